@@ -1,0 +1,772 @@
+/*
+ * rt_oracle.c -- TEST INFRASTRUCTURE ONLY (see rt_oracle.h).
+ *
+ * Scalar CPU restatement of the reference's algorithm, written from reading
+ * /root/reference (paths below are relative to that root).  Float evaluation
+ * order follows the reference expression by expression; build with
+ * -ffp-contract=off on x86-64 (SSE2: no excess precision).
+ */
+#include "rt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------------ */
+/* algebra3 vec3 (HW4/hw4/algebra3.cpp:234-400)                              */
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 vload(const float* p) { return V(p[0], p[1], p[2]); }
+static inline void vstore(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+/* operator+ :324, operator- :327 */
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+/* operator*(vec3,float) :330 and (float,vec3) :333 -- both d*a.n[i] */
+static inline v3 vmuls(v3 a, float d) { return V(d * a.x, d * a.y, d * a.z); }
+/* operator*(vec3,vec3) :342 */
+static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* operator^ :349 */
+static inline v3 vcross(v3 a, v3 b) {
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* length :295-299 */
+static inline float vlen(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+/* operator/ :345 and /= :280: float d_inv = 1./d (double divide, then float) */
+static inline v3 vdivs(v3 a, float d) {
+    float d_inv = (float)(1.0 / (double)d);
+    return V(a.x * d_inv, a.y * d_inv, a.z * d_inv);
+}
+/* normalize :301 */
+static inline v3 vnorm(v3 a) { return vdivs(a, vlen(a)); }
+
+/* ------------------------------------------------------------------------ */
+typedef struct kdnode {
+    struct kdnode *left, *right;
+    int32_t* prims; int64_t nprims;   /* kdMeshes (triangle prim ids)          */
+    int split_axis; float split_value;
+    float center[3], extend[3];
+    int is_leaf; int layer;
+    float model_scale;
+} kdnode;
+
+struct orc_scene {
+    int64_t nprim;
+    rt_prim* prims; uint8_t* type; int32_t* mat;
+    float (*nrm0)[3];            /* parse-time normal[0] copies for reset        */
+    int32_t nmat; rt_material* mats;
+    int32_t nobj; kdnode** roots;
+    int64_t nloose; int32_t* loose;
+    int32_t nlight; rt_light* lights;
+    double tol; float shadow_bias, refract_bias; uint32_t flags;
+    int64_t builded; int32_t max_depth;
+    orc_counters c;
+    /* per-pixel counters of the reference (hw4.cpp:52-54) */
+    double total_check; int check_time;
+};
+
+/* ---- KDNode::CalcBound, hw4.cpp:330-389 --------------------------------- */
+static void calc_bound(const orc_scene* s, kdnode* n) {
+    float mins[3] = { 1e9f, 1e9f, 1e9f }, maxs[3] = { -1e9f, -1e9f, -1e9f };
+    for (int64_t i = 0; i < n->nprims; i++) {
+        const float* f = s->prims[n->prims[i]].f;
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) {
+                float v = f[3 * j + k];
+                if (v < mins[k]) mins[k] = v;
+                if (v > maxs[k]) maxs[k] = v;
+            }
+    }
+    v3 c = vdivs(vadd(vload(mins), vload(maxs)), 2.0f);
+    v3 e = vsub(vload(maxs), vload(mins));
+    vstore(n->center, c); vstore(n->extend, e);
+    float temp = -1e9f;
+    for (int i = 0; i < 3; i++)
+        if (n->extend[i] > temp) { temp = n->extend[i]; n->split_axis = i; }
+}
+
+static int cmp_float(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+static kdnode* new_node(void) {
+    kdnode* n = (kdnode*)calloc(1, sizeof(kdnode));
+    n->model_scale = 2.0f;           /* KDNode ctor default, hw4.h:203 */
+    return n;
+}
+
+/* ---- KDNode::BuildKD, hw4.cpp:393-490 ----------------------------------- */
+static void build_kd(orc_scene* s, kdnode* n, int depth) {
+    n->layer = depth;
+    if (depth > s->max_depth) s->max_depth = depth;
+    s->builded++;
+    calc_bound(s, n);
+    int ax = n->split_axis;
+    int64_t np = n->nprims;
+    float* poses = (float*)malloc(sizeof(float) * 3 * (size_t)(np > 0 ? np : 1));
+    for (int64_t i = 0; i < np; i++) {
+        const float* f = s->prims[n->prims[i]].f;
+        poses[3 * i + 0] = f[0 + ax]; poses[3 * i + 1] = f[3 + ax]; poses[3 * i + 2] = f[6 + ax];
+    }
+    qsort(poses, (size_t)(3 * np), sizeof(float), cmp_float);
+    n->split_value = poses[(3 * np) / 2];
+    free(poses);
+    float split = n->split_value;
+    kdnode* L = new_node(); kdnode* R = new_node();
+    n->left = L; n->right = R;
+    L->prims = (int32_t*)malloc(sizeof(int32_t) * (size_t)(np > 0 ? np : 1));
+    R->prims = (int32_t*)malloc(sizeof(int32_t) * (size_t)(np > 0 ? np : 1));
+    int64_t match = 0;
+    for (int64_t i = 0; i < np; i++) {
+        const float* f = s->prims[n->prims[i]].f;
+        int inl = 0, inr = 0;
+        for (int j = 0; j < 3; j++) if (f[3 * j + ax] >= split) { inr = 1; break; }
+        for (int j = 0; j < 3; j++) if (f[3 * j + ax] <  split) { inl = 1; break; }
+        if (inr) R->prims[R->nprims++] = n->prims[i];
+        if (inl) L->prims[L->nprims++] = n->prims[i];
+        if (inl && inr) match++;
+    }
+    if ((float)match < (float)L->nprims / n->model_scale &&
+        (float)match < (float)R->nprims / n->model_scale) {
+        /* interior: its own list is never read again */
+        build_kd(s, L, depth + 1);
+        build_kd(s, R, depth + 1);
+    } else {
+        calc_bound(s, L); calc_bound(s, R);
+        L->layer = R->layer = depth + 1;
+        n->is_leaf = 1;
+    }
+}
+
+static void free_kd(kdnode* n) {
+    if (!n) return;
+    free_kd(n->left); free_kd(n->right);
+    free(n->prims); free(n);
+}
+
+orc_scene* orc_scene_create(const rt_scene_desc* d) {
+    orc_scene* s = (orc_scene*)calloc(1, sizeof(orc_scene));
+    s->nprim = d->nprim;
+    size_t np = (size_t)(d->nprim > 0 ? d->nprim : 1);
+    s->prims = (rt_prim*)malloc(sizeof(rt_prim) * np);
+    s->type = (uint8_t*)malloc(np); s->mat = (int32_t*)malloc(sizeof(int32_t) * np);
+    s->nrm0 = (float(*)[3])malloc(sizeof(float) * 3 * np);
+    memcpy(s->prims, d->prims, sizeof(rt_prim) * (size_t)d->nprim);
+    memcpy(s->type, d->prim_type, (size_t)d->nprim);
+    memcpy(s->mat, d->prim_material, sizeof(int32_t) * (size_t)d->nprim);
+    for (int64_t i = 0; i < d->nprim; i++) memcpy(s->nrm0[i], &s->prims[i].f[9], 12);
+    s->nmat = d->nmaterial;
+    s->mats = (rt_material*)malloc(sizeof(rt_material) * (size_t)(d->nmaterial > 0 ? d->nmaterial : 1));
+    memcpy(s->mats, d->materials, sizeof(rt_material) * (size_t)d->nmaterial);
+    s->nlight = d->nlight;
+    s->lights = (rt_light*)malloc(sizeof(rt_light) * (size_t)(d->nlight > 0 ? d->nlight : 1));
+    if (d->nlight) memcpy(s->lights, d->lights, sizeof(rt_light) * (size_t)d->nlight);
+    s->tol = d->tolerance_depth; s->shadow_bias = d->shadow_bias; s->refract_bias = d->refract_bias;
+    s->flags = d->flags;
+    uint8_t* in_obj = (uint8_t*)calloc(np, 1);
+    s->nobj = 0;
+    s->roots = (kdnode**)calloc((size_t)(d->nobject > 0 ? d->nobject : 1), sizeof(kdnode*));
+    for (int32_t o = 0; o < d->nobject; o++) {
+        kdnode* root = new_node();
+        root->prims = (int32_t*)malloc(sizeof(int32_t) * (size_t)(d->obj_count[o] > 0 ? d->obj_count[o] : 1));
+        for (int64_t i = d->obj_first[o]; i < d->obj_first[o] + d->obj_count[o]; i++)
+            if (s->type[i] == RT_PRIM_TRIANGLE) { root->prims[root->nprims++] = (int32_t)i; in_obj[i] = 1; }
+        if (root->nprims == 0) { free_kd(root); continue; }   /* hw4.cpp:731 */
+        /* hw4.cpp:736-738; the count there includes every mesh of the group */
+        float tempF = (float)(log10((double)(int)d->obj_count[o]) - 1.0f);
+        root->model_scale = tempF < 1.5f ? 1.5f : tempF;
+        build_kd(s, root, 0);
+        s->roots[s->nobj++] = root;
+    }
+    s->loose = (int32_t*)malloc(sizeof(int32_t) * np);
+    for (int64_t i = 0; i < d->nprim; i++) if (!in_obj[i]) s->loose[s->nloose++] = (int32_t)i;
+    free(in_obj);
+    return s;
+}
+
+void orc_scene_destroy(orc_scene* s) {
+    if (!s) return;
+    for (int i = 0; i < s->nobj; i++) free_kd(s->roots[i]);
+    free(s->roots); free(s->prims); free(s->type); free(s->mat); free(s->nrm0);
+    free(s->mats); free(s->lights); free(s->loose); free(s);
+}
+
+void orc_scene_reset_normals(orc_scene* s) {
+    for (int64_t i = 0; i < s->nprim; i++) memcpy(&s->prims[i].f[9], s->nrm0[i], 12);
+}
+void orc_counters_get(const orc_scene* s, orc_counters* c) { *c = s->c; }
+void orc_counters_reset(orc_scene* s) { memset(&s->c, 0, sizeof(s->c)); }
+
+static void count_flat(const kdnode* n, int64_t* nn, int64_t* nl) {
+    (*nn)++;
+    if (n->is_leaf) { *nl += n->nprims; return; }
+    if (n->left) count_flat(n->left, nn, nl);
+    if (n->right) count_flat(n->right, nn, nl);
+}
+
+void orc_scene_info(const orc_scene* s, rt_scene_info* info) {
+    memset(info, 0, sizeof(*info));
+    info->kd_nodes_built = s->builded; info->kd_max_depth = s->max_depth;
+    for (int i = 0; i < s->nobj; i++) count_flat(s->roots[i], &info->flat_nodes, &info->leaf_refs);
+    for (int64_t i = 0; i < s->nprim; i++) { if (s->type[i] == RT_PRIM_SPHERE) info->nsphere++; else info->ntri++; }
+    info->nloose = s->nloose;
+}
+
+/* pre-order, left before right (only a naming of nodes; traversal order is
+ * defined by the push order in closest()/any()) */
+static int32_t flatten_rec(const kdnode* n, orc_kd_flat* f, int64_t* nn, int64_t* nl) {
+    int32_t me = (int32_t)(*nn)++;
+    for (int k = 0; k < 3; k++) {
+        f->lo[3 * me + k] = n->center[k] - n->extend[k] / 2.0f;
+        f->hi[3 * me + k] = n->center[k] + n->extend[k] / 2.0f;
+    }
+    f->is_leaf[me] = n->is_leaf; f->left[me] = f->right[me] = -1;
+    f->leaf_first[me] = 0; f->leaf_count[me] = 0;
+    if (n->is_leaf) {
+        f->leaf_first[me] = *nl; f->leaf_count[me] = (int32_t)n->nprims;
+        memcpy(f->leaf_prims + *nl, n->prims, sizeof(int32_t) * (size_t)n->nprims);
+        *nl += n->nprims;
+    } else {
+        f->left[me] = flatten_rec(n->left, f, nn, nl);
+        f->right[me] = flatten_rec(n->right, f, nn, nl);
+    }
+    return me;
+}
+
+int orc_kd_flatten(const orc_scene* s, orc_kd_flat* f) {
+    rt_scene_info info; orc_scene_info(s, &info);
+    memset(f, 0, sizeof(*f));
+    size_t nn = (size_t)(info.flat_nodes > 0 ? info.flat_nodes : 1), nl = (size_t)(info.leaf_refs > 0 ? info.leaf_refs : 1);
+    f->lo = (float*)malloc(12 * nn); f->hi = (float*)malloc(12 * nn);
+    f->left = (int32_t*)malloc(4 * nn); f->right = (int32_t*)malloc(4 * nn); f->is_leaf = (int32_t*)malloc(4 * nn);
+    f->leaf_first = (int64_t*)malloc(8 * nn); f->leaf_count = (int32_t*)malloc(4 * nn);
+    f->leaf_prims = (int32_t*)malloc(4 * nl);
+    f->roots = (int32_t*)malloc(4 * (size_t)(s->nobj > 0 ? s->nobj : 1));
+    int64_t a = 0, b = 0;
+    for (int i = 0; i < s->nobj; i++) f->roots[i] = flatten_rec(s->roots[i], f, &a, &b);
+    f->nnode = a; f->nleafref = b; f->nroot = s->nobj;
+    return 0;
+}
+void orc_kd_flat_free(orc_kd_flat* f) {
+    free(f->lo); free(f->hi); free(f->left); free(f->right); free(f->is_leaf);
+    free(f->leaf_first); free(f->leaf_count); free(f->leaf_prims); free(f->roots);
+    memset(f, 0, sizeof(*f));
+}
+
+/* ---- KDNode::HitTest, hw4.cpp:281-328 ----------------------------------- */
+static inline void swapf(float* a, float* b) { float t = *a; *a = *b; *b = t; }
+int orc_box_test(const float c[3], const float e[3], const float o[3], const float r[3]) {
+    float tmin = ((c[0] - e[0] / 2.0f) - o[0]) / r[0];
+    float tmax = ((c[0] + e[0] / 2.0f) - o[0]) / r[0];
+    if (tmin > tmax) swapf(&tmin, &tmax);
+    float tymin = ((c[1] - e[1] / 2.0f) - o[1]) / r[1];
+    float tymax = ((c[1] + e[1] / 2.0f) - o[1]) / r[1];
+    if (tymin > tymax) swapf(&tymin, &tymax);
+    if ((tmin > tymax) || (tymin > tmax)) return 0;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = ((c[2] - e[2] / 2.0f) - o[2]) / r[2];
+    float tzmax = ((c[2] + e[2] / 2.0f) - o[2]) / r[2];
+    if (tzmin > tzmax) swapf(&tzmin, &tzmax);
+    if ((tmin > tzmax) || (tzmin > tmax)) return 0;
+    return 1;
+}
+
+/* ---- Triangle::IntersectionTest (non-culling branch), hw4.cpp:171-231 ---- */
+#define EPSILON 0.000001   /* hw4.cpp:18 (double) */
+int orc_tri_test(const float vt[9], const float o[3], const float d[3], float point[3]) {
+    v3 v0 = vload(vt), v1 = vload(vt + 3), v2 = vload(vt + 6), dir = vload(d), ori = vload(o);
+    v3 edge1 = vsub(v1, v0), edge2 = vsub(v2, v0);
+    v3 pvec = vcross(dir, edge2);
+    float det = vdot(edge1, pvec);
+    if (det > -EPSILON && det < EPSILON) return 0;
+    float detInv = 1.0f / det;
+    v3 tvec = vsub(ori, v0);
+    float u = vdot(tvec, pvec) * detInv;
+    if (u < 0 || u > 1.0f) return 0;
+    v3 qvec = vcross(tvec, edge1);
+    float v = vdot(dir, qvec) * detInv;
+    if (v < 0 || u + v > 1.0f) return 0;
+    float t = vdot(edge2, qvec) * detInv;
+    if (t < 0) return 0;
+    vstore(point, vadd(ori, vmuls(dir, t)));
+    return 1;
+}
+
+/* ---- Sphere::IntersectionTest, hw4.cpp:73-116 == final.cpp:49-92 --------- */
+int orc_sphere_test(const float c[3], float radius, const float o[3], const float d[3], float point[3]) {
+    v3 ori = vload(o), dir = vload(d);
+    v3 h = vsub(vload(c), ori);
+    float mu = vdot(h, dir);
+    float delta = (mu * mu) - vdot(h, h) + (radius * radius);
+    if (delta < 0) return 0;
+    float t1 = mu + sqrtf(delta);
+    float t2 = mu - sqrtf(delta);
+    if (t1 <= 0 && t2 <= 0) return 0;
+    float t;
+    if (t1 >= 0 && t2 < 0) t = t1;
+    else if (t1 < 0 && t2 >= 0) t = t2;
+    else t = t1 < t2 ? t1 : t2;
+    vstore(point, vadd(ori, vmuls(dir, t)));   /* rayOri + t*rayDir */
+    return 1;
+}
+
+static int prim_test(orc_scene* s, int32_t p, const float o[3], const float d[3], float pt[3]) {
+    s->c.tri_tests++;
+    if (s->type[p] == RT_PRIM_SPHERE) return orc_sphere_test(s->prims[p].f, s->prims[p].f[3], o, d, pt);
+    return orc_tri_test(s->prims[p].f, o, d, pt);
+}
+
+/* GetNormal: Triangle hw4.cpp:122-137 normalises the stored normal[0] in place
+ * on every call; Sphere :118-120 */
+static v3 get_normal(orc_scene* s, int32_t p, v3 point) {
+    float* f = s->prims[p].f;
+    if (s->type[p] == RT_PRIM_SPHERE) return vnorm(vsub(point, vload(f)));
+    v3 n = vnorm(vload(f + 9));
+    vstore(f + 9, n);
+    return n;
+}
+
+static inline int node_hit(orc_scene* s, const kdnode* n, const float o[3], const float d[3]) {
+    s->c.box_tests++;
+    return orc_box_test(n->center, n->extend, o, d);
+}
+
+#define KD_STACK 256
+
+/* closest hit: hw4.cpp:799-871 (objects), final.cpp:792-816 (plain list) */
+static int32_t closest(orc_scene* s, v3 ori, v3 dir, float* nearest_out, v3* hit_out) {
+    float o[3], d[3]; vstore(o, ori); vstore(d, dir);
+    float nearestDis = 1e9f; int32_t nearest = -1; v3 hitPoint = V(0, 0, 0);
+    int culling = (s->flags & RT_SCENE_CULLING) != 0;
+    s->check_time++;
+    for (int j = 0; j < s->nobj; j++) {
+        kdnode* root = s->roots[j];
+        if (!node_hit(s, root, o, d)) continue;
+        kdnode* stack[KD_STACK]; int sp = 0;
+        stack[sp++] = root;
+        while (sp > 0) {
+            kdnode* node = stack[--sp];
+            if (!node_hit(s, node, o, d)) continue;
+            if (!node->is_leaf) {
+                if (node->left && node_hit(s, node->left, o, d)) stack[sp++] = node->left;
+                if (node->right && node_hit(s, node->right, o, d)) stack[sp++] = node->right;
+            } else {
+                s->total_check += (int)node->nprims;
+                s->c.leaf_refs_read += node->nprims;
+                for (int64_t i = 0; i < node->nprims; i++) {
+                    float pt[3];
+                    if (prim_test(s, node->prims[i], o, d, pt)) {
+                        v3 v = vload(pt);
+                        float len = vlen(vsub(ori, v));
+                        if (len < nearestDis && len > s->tol &&
+                            (!culling || vdot(get_normal(s, node->prims[i], v), dir) < 0)) {
+                            nearest = node->prims[i]; nearestDis = len; hitPoint = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    for (int64_t i = 0; i < s->nloose; i++) {
+        float pt[3]; int32_t p = s->loose[i];
+        if (prim_test(s, p, o, d, pt)) {
+            v3 v = vload(pt);
+            float len = vlen(vsub(ori, v));
+            if (len < nearestDis && len > s->tol &&
+                (!culling || vdot(get_normal(s, p, v), dir) < 0)) {
+                nearest = p; nearestDis = len; hitPoint = v;
+            }
+        }
+    }
+    *nearest_out = nearestDis; *hit_out = hitPoint;
+    return nearest;
+}
+
+/* any hit: hw4.cpp:986-1049 (tmax<0: no limit, Q4) / final.cpp:997-1016 */
+static int any_hit(orc_scene* s, v3 point, v3 rayDir, int use_tmax, float tLight) {
+    float o[3], d[3]; vstore(o, point); vstore(d, rayDir);
+    float nearestDis = 1e9f;
+    s->check_time++;
+    for (int j = 0; j < s->nobj; j++) {
+        kdnode* root = s->roots[j];
+        if (!node_hit(s, root, o, d)) continue;
+        kdnode* stack[KD_STACK]; int sp = 0;
+        stack[sp++] = root;
+        while (sp > 0) {
+            kdnode* node = stack[--sp];
+            if (!node_hit(s, node, o, d)) continue;
+            if (!node->is_leaf) {
+                if (node->left && node_hit(s, node->left, o, d)) stack[sp++] = node->left;
+                if (node->right && node_hit(s, node->right, o, d)) stack[sp++] = node->right;
+            } else {
+                s->total_check += (int)node->nprims;
+                s->c.leaf_refs_read += node->nprims;
+                for (int64_t i = 0; i < node->nprims; i++) {
+                    float pt[3]; int32_t p = node->prims[i];
+                    if (use_tmax && (double)s->mats[s->mat[p]].refract > 0.1) continue;
+                    if (prim_test(s, p, o, d, pt)) {
+                        float len = vlen(vsub(point, vload(pt)));
+                        if (len < (use_tmax ? tLight : nearestDis) && len > s->tol) return 1;
+                    }
+                }
+            }
+        }
+    }
+    for (int64_t i = 0; i < s->nloose; i++) {
+        float pt[3]; int32_t p = s->loose[i];
+        if (use_tmax && (double)s->mats[s->mat[p]].refract > 0.1) continue;
+        if (prim_test(s, p, o, d, pt)) {
+            float len = vlen(vsub(point, vload(pt)));
+            if (len < (use_tmax ? tLight : nearestDis) && len > s->tol) return 1;
+        }
+    }
+    return 0;
+}
+
+void orc_trace_closest(orc_scene* s, const rt_ray* rays, int64_t n, rt_hit* out) {
+    for (int64_t i = 0; i < n; i++) {
+        float len; v3 hp;
+        int32_t p = closest(s, vload(rays[i].o), vload(rays[i].d), &len, &hp);
+        out[i].prim = p; out[i].len = len; vstore(out[i].p, hp);
+    }
+}
+
+void orc_trace_any(orc_scene* s, const rt_ray* rays, const float* tmax, int64_t n, uint8_t* occ) {
+    for (int64_t i = 0; i < n; i++)
+        occ[i] = (uint8_t)any_hit(s, vload(rays[i].o), vload(rays[i].d), tmax != NULL, tmax ? tmax[i] : 0.0f);
+}
+
+/* ---- camera: hw4.cpp:242-276, 559 ---------------------------------------- */
+void orc_camera_setup(const float eye[3], const float view_raw[3], float fov_deg,
+                      int resx, int resy, rt_camera* cam) {
+    const float planeDistance = 1.0f;           /* hw4.cpp:25 */
+    v3 up = V(0, 1.0f, 0);                      /* hw4.cpp:47 */
+    v3 center = vload(eye);
+    v3 view = vnorm(vload(view_raw));           /* hw4.cpp:559 */
+    float fovX = fov_deg, fovY = fov_deg / 1.0f;
+    v3 planeCenter = vadd(center, vmuls(vdivs(view, vlen(view)), planeDistance));
+    v3 X = vnorm(vcross(up, view));
+    v3 Y = vnorm(vcross(X, view));
+    float thetaX = fovX / 2.0f, thetaY = fovY / 2.0f;
+    float halfWidth = planeDistance * tanf(thetaX * (3.14159f / 180.0f));
+    float halfHeight = (float)(planeDistance * tan(thetaY * (3.14159 / 180.0f)));
+    v3 c0 = vsub(vsub(planeCenter, vmuls(X, halfWidth)), vmuls(Y, halfHeight));
+    v3 c1 = vsub(vadd(planeCenter, vmuls(X, halfWidth)), vmuls(Y, halfHeight));
+    v3 c2 = vadd(vsub(planeCenter, vmuls(X, halfWidth)), vmuls(Y, halfHeight));
+    v3 c3 = vadd(vadd(planeCenter, vmuls(X, halfWidth)), vmuls(Y, halfHeight));
+    vstore(cam->center, center);
+    vstore(cam->corners[0], c0); vstore(cam->corners[1], c1);
+    vstore(cam->corners[2], c2); vstore(cam->corners[3], c3);
+    vstore(cam->xaxis, X); vstore(cam->yaxis, Y);
+    cam->resx = resx; cam->resy = resy;
+}
+
+void orc_primary_ray(const rt_camera* cam, float px, float py, rt_ray* ray) {
+    v3 c0 = vload(cam->corners[0]), c1 = vload(cam->corners[1]), c2 = vload(cam->corners[2]);
+    v3 X = vload(cam->xaxis), Y = vload(cam->yaxis), eye = vload(cam->center);
+    float pixelWidth = vlen(vsub(c1, c0)) / ((float)cam->resx);
+    float pixelHeight = vlen(vsub(c0, c2)) / ((float)cam->resy);
+    v3 pc = vadd(vadd(vadd(vadd(c0, vmuls(X, 0.5f * pixelWidth)), vmuls(Y, 0.5f * pixelHeight)),
+                      vmuls(X, px * pixelWidth)), vmuls(Y, py * pixelHeight));
+    v3 dir = vnorm(vsub(pc, eye));
+    vstore(ray->o, eye); vstore(ray->d, dir);
+}
+
+/* std::max(a,b) = (a<b)?b:a : a NaN first argument is returned as is */
+static inline float maxf_std(float a, float b) { return (a < b) ? b : a; }
+
+/* ---- SimpleMeshRayTrace, hw4.cpp:794-955 --------------------------------- */
+typedef struct { orc_scene* s; const rt_camera* cam; const rt_params* p; int hit_any; int32_t first_prim; } rctx;
+
+static v3 whitted(rctx* c, v3 ori, v3 dir, int depth, float currentNr) {
+    orc_scene* s = c->s;
+    if (depth > c->p->max_depth) return V(0, 0, 0);
+    v3 colour = V(0, 0, 0), hitPoint; float nearestDis;
+    int32_t prim = closest(s, ori, dir, &nearestDis, &hitPoint);
+    v3 diffuse = V(0, 0, 0), specular = V(0, 0, 0);
+    if (depth == 0) c->first_prim = prim;
+    if (prim < 0) return colour;
+    if (depth == 0) c->hit_any = 1;
+    const rt_material* m = &s->mats[s->mat[prim]];
+    v3 surf = vload(m->surf);
+    v3 normal = get_normal(s, prim, hitPoint);
+    if (vdot(normal, dir) > 0) normal = vmuls(normal, -1.0f);
+    if (!c->p->primary_only && m->reflect > 0.0001f) {
+        float dot = vdot(dir, normal);
+        v3 reflected = vsub(dir, vmuls(normal, 2 * dot));
+        s->c.rays_reflect++;
+        v3 rc = whitted(c, hitPoint, reflected, depth + 1, currentNr);
+        colour = vadd(colour, vmuls(rc, m->reflect));
+    }
+    if (!c->p->primary_only && (double)m->refract > 0.0001) {
+        float n1 = currentNr, n2 = m->Nr;
+        float cos1 = vdot(dir, normal);
+        float sin2 = (n1 / n2) * sqrtf(1 - (cos1 * cos1));
+        v3 transmitted = vnorm(vadd(vmuls(dir, n1 / n2), vmuls(normal, cos1 * (n1 / n2) - sqrtf(1 - (sin2 * sin2)))));
+        v3 displacePoint = vsub(hitPoint, vmuls(normal, s->refract_bias));
+        s->c.rays_refract++;
+        v3 rc = whitted(c, displacePoint, transmitted, depth + 1, n2);
+        colour = vadd(colour, vmuls(rc, m->refract));
+    }
+    v3 ambient = vmuls(vmuls(surf, c->p->ambient_intensity), m->Ka);
+    colour = vadd(colour, ambient);
+    for (int i = 0; i < s->nlight; i++) {
+        v3 lpos = vload(s->lights[i].pos);
+        /* IsInShadow, hw4.cpp:957-967 */
+        v3 point = vadd(hitPoint, vmuls(normal, s->shadow_bias));
+        v3 rayDir = vnorm(vsub(lpos, point));
+        s->c.rays_shadow++;
+        if (!any_hit(s, point, rayDir, 0, 0.0f)) {
+            v3 toLight = vnorm(vsub(lpos, hitPoint));
+            float dot = maxf_std(vdot(toLight, normal), 0.0f);
+            v3 isurf = vmuls(surf, s->lights[i].intensity);
+            diffuse = vmuls(isurf, m->Kd * dot);
+            v3 eyeVec = vnorm(vsub(vload(c->cam->center), hitPoint));
+            v3 halfVec = vnorm(vadd(eyeVec, toLight));
+            dot = maxf_std(vdot(halfVec, normal), 0.0f);
+            specular = vmuls(vmuls(isurf, m->Ks), powf(dot, m->specularity));
+        }
+        colour = vadd(vadd(colour, diffuse), specular);
+    }
+    return colour;
+}
+
+/* float -> unsigned char as x86-64 gcc does it (cvttss2si, low byte) */
+static inline uint8_t quant(float c) {
+    if (c > 1.0f) return 255;
+    float v = c * 255.0f;
+    if (!(v > -2147483648.0f && v < 2147483648.0f)) return 0;   /* NaN / out of range: 0x80000000 */
+    return (uint8_t)(int32_t)v;
+}
+
+/* GenerateColorImage, hw4.cpp:1081-1124 */
+void orc_render_whitted(orc_scene* s, const rt_camera* cam, const rt_params* p,
+                        uint8_t* rgb8, int32_t* hit_ids, float* radiance) {
+    rctx c; c.s = s; c.cam = cam; c.p = p;
+    s->c.average_check = 0;
+    for (int x = 0; x < cam->resx; x++) {
+        for (int y = 0; y < cam->resy; y++) {
+            s->total_check = 0; s->check_time = 0;
+            rt_ray r; orc_primary_ray(cam, (float)x, (float)y, &r);
+            c.hit_any = 0; c.first_prim = -1;
+            s->c.rays_primary++;
+            v3 col = whitted(&c, vload(r.o), vload(r.d), 0, p->start_nr);
+            s->c.average_check += (s->total_check / (double)s->check_time) / (double)(cam->resx * cam->resy);
+            size_t px = (size_t)x + (size_t)y * (size_t)cam->resx;
+            if (c.hit_any) {
+                rgb8[3 * px + 0] = quant(col.x); rgb8[3 * px + 1] = quant(col.y); rgb8[3 * px + 2] = quant(col.z);
+            } else {
+                rgb8[3 * px + 0] = (uint8_t)p->background[0]; rgb8[3 * px + 1] = (uint8_t)p->background[1];
+                rgb8[3 * px + 2] = (uint8_t)p->background[2];
+            }
+            if (hit_ids) hit_ids[px] = c.first_prim;
+            if (radiance) { radiance[3 * px] = col.x; radiance[3 * px + 1] = col.y; radiance[3 * px + 2] = col.z; }
+        }
+    }
+}
+
+/* ======================================================================== */
+/* photon map, Final/photon/photon.cpp                                       */
+#define PM_PI 3.141592     /* parameter.h:6 */
+
+/* InitDirectionTable, photon.cpp:40-50 */
+void orc_direction_tables(float* cost, float* sint, float* cosp, float* sinp) {
+    for (int i = 0; i < 256; i++) {
+        double angle = (double)i * (1.0 / 256.0) * PM_PI;
+        cost[i] = (float)cos(angle); sint[i] = (float)sin(angle);
+        cosp[i] = (float)cos(2.0 * angle); sinp[i] = (float)sin(2.0 * angle);
+    }
+}
+
+/* direction part of AddPhoton, photon.cpp:846,869-882 */
+void orc_photon_quantize_dir(const float dir[3], uint8_t* phi_out, uint8_t* theta_out, float ndir[3]) {
+    v3 d = vnorm(vload(dir));
+    vstore(ndir, d);
+    int phi = (int)(atan2((double)d.y, (double)d.x) * (256.0 / (2.0 * M_PI)));
+    int theta = (int)(acos((double)d.z) * (256.0 / PM_PI));
+    if (phi > 255) phi = 255;
+    if (phi < 0) phi = (unsigned char)(phi + 256);
+    *phi_out = (unsigned char)phi;
+    if (theta > 255) theta = 255;
+    *theta_out = (unsigned char)theta;
+}
+
+/* median_split, photon.cpp:224-254 (p holds 1-based photon indices) */
+static void median_split(const rt_photon* ph, int64_t* p, int64_t start, int64_t ending, int64_t median, int axis) {
+    int64_t left = start, right = ending;
+    while (right > left) {
+        const float v = ph[p[right]].position[axis];
+        int64_t i = left - 1, j = right;
+        for (;;) {
+            while (ph[p[++i]].position[axis] < v) ;
+            while (ph[p[--j]].position[axis] > v && j > left) ;
+            if (i >= j) break;
+            int64_t t = p[i]; p[i] = p[j]; p[j] = t;
+        }
+        { int64_t t = p[i]; p[i] = p[right]; p[right] = t; }
+        if (i >= median) right = i - 1;
+        if (i <= median) left = i + 1;
+    }
+}
+
+/* balance_segment, photon.cpp:171-222 */
+static void balance_segment(rt_photon* ph, int64_t* pbal, int64_t* porg, int64_t index,
+                            int64_t start, int64_t ending, float bbMin[3], float bbMax[3]) {
+    int64_t median = 1;
+    while ((4 * median) <= (ending - start + 1)) median += median;
+    if ((3 * median) <= (ending - start + 1)) { median += median; median += start - 1; }
+    else median = ending - median + 1;
+    int axis = 2;
+    if ((bbMax[0] - bbMin[0]) > (bbMax[1] - bbMin[1]) && (bbMax[0] - bbMin[0]) > (bbMax[2] - bbMin[2])) axis = 0;
+    else if ((bbMax[1] - bbMin[1]) > (bbMax[2] - bbMin[2])) axis = 1;
+    median_split(ph, porg, start, ending, median, axis);
+    pbal[index] = porg[median];
+    ph[pbal[index]].plane = (int16_t)axis;
+    if (median > start) {
+        if (start < median - 1) {
+            const float tmp = bbMax[axis];
+            bbMax[axis] = ph[pbal[index]].position[axis];
+            balance_segment(ph, pbal, porg, 2 * index, start, median - 1, bbMin, bbMax);
+            bbMax[axis] = tmp;
+        } else pbal[2 * index] = porg[start];
+    }
+    if (median < ending) {
+        if (median + 1 < ending) {
+            const float tmp = bbMin[axis];
+            bbMin[axis] = ph[pbal[index]].position[axis];
+            balance_segment(ph, pbal, porg, 2 * index + 1, median + 1, ending, bbMin, bbMax);
+            bbMin[axis] = tmp;
+        } else pbal[2 * index + 1] = porg[ending];
+    }
+}
+
+/* PhotonMap::balance, photon.cpp:133-169.  The in-place permutation loop
+ * :145-165 is equivalent to photons_new[j] = photons_old[pa1[j]].  Bounding box
+ * stays at the constructor's values (photon.cpp:263-264,856-859: never updated). */
+void orc_pmap_balance(rt_photon* photons, int64_t n) {
+    if (n > 1) {
+        int64_t* pa1 = (int64_t*)calloc((size_t)(2 * n + 4), sizeof(int64_t));
+        int64_t* pa2 = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + 1));
+        for (int64_t i = 0; i <= n; i++) pa2[i] = i;
+        float bbMin[3] = { -1e9f, -1e9f, -1e9f }, bbMax[3] = { 1e9f, 1e9f, 1e9f };
+        balance_segment(photons, pa1, pa2, 1, 1, n, bbMin, bbMax);
+        free(pa2);
+        rt_photon* tmp = (rt_photon*)malloc(sizeof(rt_photon) * (size_t)(n + 1));
+        memcpy(tmp, photons, sizeof(rt_photon) * (size_t)(n + 1));
+        for (int64_t j = 1; j <= n; j++) photons[j] = tmp[pa1[j]];
+        free(tmp); free(pa1);
+    }
+}
+
+/* LocatePhoton, photon.cpp:53-131 */
+typedef struct { int max, found, got_heap; float pos[3]; float* dist2; int32_t* index; int64_t visits; } nearest_t;
+
+static void locate(const rt_photon* ph, int64_t half, nearest_t* np, int64_t index) {
+    const rt_photon* p = &ph[index];
+    float dist1;
+    np->visits++;
+    if (index < half) {
+        dist1 = np->pos[p->plane] - p->position[p->plane];
+        if (dist1 > 0.0) {
+            locate(ph, half, np, 2 * index + 1);
+            if (dist1 * dist1 < np->dist2[0]) locate(ph, half, np, 2 * index);
+        } else {
+            locate(ph, half, np, 2 * index);
+            if (dist1 * dist1 < np->dist2[0]) locate(ph, half, np, 2 * index + 1);
+        }
+    }
+    dist1 = p->position[0] - np->pos[0];
+    float dist2 = dist1 * dist1;
+    dist1 = p->position[1] - np->pos[1];
+    dist2 += dist1 * dist1;
+    dist1 = p->position[2] - np->pos[2];
+    dist2 += dist1 * dist1;
+    if (dist2 < np->dist2[0]) {
+        if (np->found < np->max) {
+            np->found++;
+            np->dist2[np->found] = dist2;
+            np->index[np->found] = (int32_t)index;
+        } else {
+            int j, parent;
+            if (np->got_heap == 0) {
+                float dst2; int32_t phot;
+                int half_found = np->found >> 1;
+                for (int k = half_found; k >= 1; k--) {
+                    parent = k; phot = np->index[k]; dst2 = np->dist2[k];
+                    while (parent <= half_found) {
+                        j = parent + parent;
+                        if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+                        if (dst2 >= np->dist2[j]) break;
+                        np->dist2[parent] = np->dist2[j]; np->index[parent] = np->index[j];
+                        parent = j;
+                    }
+                    np->dist2[parent] = dst2; np->index[parent] = phot;
+                }
+                np->got_heap = 1;
+            }
+            parent = 1; j = 2;
+            while (j <= np->found) {
+                if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+                if (dist2 > np->dist2[j]) break;
+                np->dist2[parent] = np->dist2[j]; np->index[parent] = np->index[j];
+                parent = j; j += j;
+            }
+            np->index[parent] = (int32_t)index; np->dist2[parent] = dist2;
+            np->dist2[0] = np->dist2[1];
+        }
+    }
+}
+
+int orc_pmap_locate(const rt_photon* heap, int64_t n, const float pos[3], int k, float maxDist,
+                    int32_t* idx, float* dist2, float* radius2, int64_t* visits) {
+    nearest_t np;
+    np.dist2 = (float*)malloc(sizeof(float) * (size_t)(k + 1));
+    np.index = (int32_t*)malloc(sizeof(int32_t) * (size_t)(k + 1));
+    np.pos[0] = pos[0]; np.pos[1] = pos[1]; np.pos[2] = pos[2];
+    np.max = k; np.found = 0; np.got_heap = 0; np.visits = 0;
+    np.dist2[0] = maxDist * maxDist;
+    int64_t half = n / 2 - 1;                    /* photon.cpp:168 */
+    if (n >= 1) locate(heap, half, &np, 1);
+    for (int i = 0; i < k; i++) { idx[i] = i < np.found ? np.index[i + 1] : -1; dist2[i] = i < np.found ? np.dist2[i + 1] : 0.0f; }
+    if (radius2) *radius2 = np.dist2[0];
+    if (visits) *visits += np.visits;
+    int f = np.found;
+    free(np.dist2); free(np.index);
+    return f;
+}
+
+void orc_pmap_knn(const rt_photon* heap, int64_t n, const float* pos3, int64_t q, int k, float maxDist,
+                  int32_t* idx, float* dist2, int32_t* found, float* radius2, int64_t* visits) {
+    for (int64_t i = 0; i < q; i++)
+        found[i] = orc_pmap_locate(heap, n, pos3 + 3 * i, k, maxDist, idx + i * k, dist2 + i * k,
+                                   radius2 ? radius2 + i : NULL, visits);
+}
+
+/* CalcIrradiance BALANCE_TREE branch, photon.cpp:391-441 */
+void orc_pmap_irradiance(const rt_photon* heap, int64_t n, const float* pos3, const float* nrm3,
+                         int64_t q, int k, float maxDist, float* rgb) {
+    static float cost[256], sint[256], cosp[256], sinp[256]; static int init = 0;
+    if (!init) { orc_direction_tables(cost, sint, cosp, sinp); init = 1; }
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)k);
+    float* d2 = (float*)malloc(sizeof(float) * (size_t)k);
+    for (int64_t i = 0; i < q; i++) {
+        float r2; const float* nr = nrm3 + 3 * i;
+        int found = orc_pmap_locate(heap, n, pos3 + 3 * i, k, maxDist, idx, d2, &r2, NULL);
+        float ir[3] = { 0, 0, 0 };
+        if (found >= 8) {
+            for (int j = 0; j < found; j++) {
+                const rt_photon* p = &heap[idx[j]];
+                float px = sint[p->theta] * cosp[p->phi], py = sint[p->theta] * sinp[p->phi], pz = cost[p->theta];
+                if ((px * nr[0] + py * nr[1] + pz * nr[2]) < 0.0f) {
+                    ir[0] += p->power[0]; ir[1] += p->power[1]; ir[2] += p->power[2];
+                }
+            }
+            const float tmp = (float)((1.0f / PM_PI) / (r2));
+            ir[0] *= tmp; ir[1] *= tmp; ir[2] *= tmp;
+        }
+        rgb[3 * i] = ir[0]; rgb[3 * i + 1] = ir[1]; rgb[3 * i + 2] = ir[2];
+    }
+    free(idx); free(d2);
+}

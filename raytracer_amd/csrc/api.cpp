@@ -1,0 +1,313 @@
+// api.cpp -- the extern "C" surface of librt_hip.so (include/rt_hip.h): scene
+// lifetime, traversal entry points, staging of caller-owned host buffers.
+// There is no CPU path here: every entry point needs a gfx950 device.
+#include "rt_scene.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+static thread_local std::string g_err;
+
+int rt_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int rt_hipfail(hipError_t e, const char* what) {
+    return rt_fail(RT_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+DeviceGuard::DeviceGuard(int dev) : prev(-1), ok(false) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) return;
+    ok = true; cur = dev;
+}
+DeviceGuard::~DeviceGuard() { if (ok && prev >= 0 && prev != cur) (void)hipSetDevice(prev); }
+
+int rt_scene::dev_alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    allocs.push_back(*p);
+    device_bytes += (int64_t)bytes;
+    return RT_OK;
+}
+
+// grow-only scratch, reused across calls (one host thread per scene)
+int rt_scene::scratch(int slot, size_t bytes, void** p) {
+    if (slot < 0 || slot >= RT_NSCRATCH) return rt_fail(RT_E_INVALID, "bad scratch slot");
+    if (scratch_cap[slot] < bytes) {
+        if (scratch_ptr[slot]) (void)hipFree(scratch_ptr[slot]);
+        scratch_ptr[slot] = nullptr; scratch_cap[slot] = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&scratch_ptr[slot], want);
+        if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(%zu) scratch: %s", want, hipGetErrorString(e));
+        scratch_cap[slot] = want;
+    }
+    *p = scratch_ptr[slot];
+    return RT_OK;
+}
+
+template <class T>
+static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
+    void* p = nullptr;
+    int rc = s->dev_alloc(&p, v.size() * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) {
+        hipError_t e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(scene)");
+    }
+    *out = (const T*)p;
+    return RT_OK;
+}
+
+static bool is_gfx950(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_init(int ndev_wanted) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return rt_fail(RT_E_NODEVICE, "no HIP device visible (%s); librt_hip has no CPU path",
+                       e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    int good = 0;
+    for (int d = 0; d < n; ++d) good += is_gfx950(d) ? 1 : 0;
+    if (good == 0) return rt_fail(RT_E_NODEVICE, "no gfx950 device among %d HIP devices", n);
+    if (ndev_wanted > good) return rt_fail(RT_E_NODEVICE, "%d devices wanted, %d gfx950 visible", ndev_wanted, good);
+    return good;
+}
+
+int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+    if (!d || !out) return rt_fail(RT_E_INVALID, "rt_scene_create: NULL argument");
+    *out = nullptr;
+    if (d->abi_version != RT_ABI_VERSION) return rt_fail(RT_E_INVALID, "abi_version %d != %d", d->abi_version, RT_ABI_VERSION);
+    if (d->nprim < 0 || d->nmaterial <= 0 || d->nobject < 0 || d->nlight < 0)
+        return rt_fail(RT_E_INVALID, "rt_scene_create: negative count or no material");
+    if (d->nprim > 0 && (!d->prims || !d->prim_type || !d->prim_material))
+        return rt_fail(RT_E_INVALID, "rt_scene_create: NULL primitive arrays");
+    if (!d->materials || (d->nobject > 0 && (!d->obj_first || !d->obj_count)) || (d->nlight > 0 && !d->lights))
+        return rt_fail(RT_E_INVALID, "rt_scene_create: NULL array");
+    if (d->nprim >= (int64_t)1 << 30) return rt_fail(RT_E_LIMIT, "more than 2^30 primitives");
+
+    int dev = d->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess)
+        return rt_fail(RT_E_NODEVICE, "no HIP device; librt_hip has no CPU path");
+    if (!is_gfx950(dev)) return rt_fail(RT_E_NODEVICE, "device %d is not a usable gfx950", dev);
+
+    HostFlatScene flat;
+    std::string err;
+    int rc;
+    try {
+        rc = rt_build_flat_scene(d, &flat, &err);
+    } catch (const std::bad_alloc&) {
+        return rt_fail(RT_E_NOMEM, "host allocation failed while building the KD-trees");
+    }
+    if (rc) return rt_fail(rc, "%s", err.c_str());
+
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return rt_fail(RT_E_NOMEM, "host allocation failed");
+    s->device = dev;
+    DeviceGuard g(dev);
+    if (!g.ok) { delete s; return rt_fail(RT_E_NODEVICE, "hipSetDevice(%d) failed", dev); }
+
+    std::vector<DevMaterial> mats((size_t)d->nmaterial);
+    for (int i = 0; i < d->nmaterial; ++i) {
+        const rt_material& m = d->materials[i];
+        DevMaterial& o = mats[(size_t)i];
+        memcpy(o.surf, m.surf, 12);
+        o.Ka = m.Ka; o.Kd = m.Kd; o.Ks = m.Ks; o.specularity = m.specularity;
+        o.reflect = m.reflect; o.refract = m.refract; o.Nr = m.Nr; o.pad[0] = o.pad[1] = 0;
+    }
+    std::vector<DevLight> lights((size_t)d->nlight);
+    for (int i = 0; i < d->nlight; ++i) {
+        const rt_light& l = d->lights[i];
+        DevLight& o = lights[(size_t)i];
+        memcpy(o.pos, l.pos, 12); o.intensity = l.intensity; memcpy(o.color, l.color, 12); o.type = l.type;
+        memcpy(o.dir1, l.dir1, 12); o.size1 = l.size1; memcpy(o.dir2, l.dir2, 12); o.size2 = l.size2;
+    }
+    s->host_lights.assign(d->lights, d->lights + d->nlight);
+    std::vector<int32_t> pmat(d->prim_material, d->prim_material + d->nprim);
+    std::vector<uint8_t> ptype(d->prim_type, d->prim_type + d->nprim);
+
+    DevSceneView& v = s->view;
+    memset(&v, 0, sizeof v);
+    rc = upload(s, flat.nodes, &v.nodes);
+    if (!rc) rc = upload(s, flat.leaf_range, &v.leaf_range);
+    if (!rc) rc = upload(s, flat.leaf_tris, &v.leaf_tris);
+    if (!rc) rc = upload(s, flat.loose, &v.loose);
+    if (!rc) rc = upload(s, flat.prim_normal, &v.prim_normal);
+    if (!rc) rc = upload(s, flat.prim_geom, &v.prim_geom);
+    if (!rc) rc = upload(s, pmat, &v.prim_material);
+    if (!rc) rc = upload(s, ptype, &v.prim_type);
+    if (!rc) rc = upload(s, mats, &v.materials);
+    if (!rc) rc = upload(s, lights, &v.lights);
+    if (rc) { rt_scene_destroy(s); return rc; }
+    v.nnodes = (int32_t)flat.nodes.size();
+    v.nloose = (int32_t)flat.loose.size();
+    v.nlights = d->nlight;
+    v.tol_f = rt_float_above(d->tolerance_depth);
+    v.culling = (d->flags & RT_SCENE_CULLING) ? 1 : 0;
+    v.shadow_bias = d->shadow_bias; v.refract_bias = d->refract_bias;
+    s->eps_f = rt_float_above(0.000001);          // `epsilon`, hw4.cpp:18
+    s->nprim = d->nprim;
+
+    rt_scene_info& inf = s->info;
+    memset(&inf, 0, sizeof inf);
+    inf.kd_nodes_built = flat.kd_nodes_built; inf.kd_max_depth = flat.kd_max_depth;
+    inf.flat_nodes = (int64_t)flat.nodes.size(); inf.leaf_refs = (int64_t)flat.leaf_tris.size();
+    inf.ntri = flat.ntri; inf.nsphere = flat.nsphere; inf.nloose = (int64_t)flat.loose.size();
+    inf.device_bytes = s->device_bytes;
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* s) {
+    if (!s) return RT_OK;
+    DeviceGuard g(s->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    for (int i = 0; i < RT_NSCRATCH; ++i) if (s->scratch_ptr[i]) (void)hipFree(s->scratch_ptr[i]);
+    for (int w = 0; w < 2; ++w) if (s->pmap[w].d_photons) (void)hipFree(s->pmap[w].d_photons);
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_info_get(const rt_scene* s, rt_scene_info* info) {
+    if (!s || !info) return rt_fail(RT_E_INVALID, "rt_scene_info_get: NULL argument");
+    *info = s->info;
+    info->device_bytes = s->device_bytes;
+    return RT_OK;
+}
+
+// ---- traversal ------------------------------------------------------------
+
+int rt_trace_closest_dev(rt_scene* s, const rt_ray* d_rays, int64_t n, rt_hit* d_out, void* stream) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return rt_fail(RT_E_INVALID, "rt_trace_closest_dev: bad argument");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    hipError_t e = rtk_trace_closest(s->view, d_rays, nullptr, n, s->eps_f, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) return rt_hipfail(e, "k_trace_closest");
+    return RT_OK;
+}
+
+int rt_trace_closest(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit* out) {
+    if (!s || n < 0 || (n > 0 && (!rays || !out))) return rt_fail(RT_E_INVALID, "rt_trace_closest: bad argument");
+    if (n == 0) return RT_OK;
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    void *dr, *dh; int rc;
+    if ((rc = s->scratch(0, (size_t)n * sizeof(rt_ray), &dr))) return rc;
+    if ((rc = s->scratch(1, (size_t)n * sizeof(rt_hit), &dh))) return rc;
+    hipError_t e = hipMemcpy(dr, rays, (size_t)n * sizeof(rt_ray), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(rays)");
+    e = rtk_trace_closest(s->view, (const rt_ray*)dr, nullptr, n, s->eps_f, (rt_hit*)dh, nullptr);
+    if (e != hipSuccess) return rt_hipfail(e, "k_trace_closest");
+    e = hipMemcpy(out, dh, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(hits)");
+    return RT_OK;
+}
+
+int rt_trace_any_dev(rt_scene* s, const rt_ray* d_rays, const float* d_tmax, int64_t n, uint8_t* d_occ, void* stream) {
+    if (!s || n < 0 || (n > 0 && (!d_rays || !d_occ))) return rt_fail(RT_E_INVALID, "rt_trace_any_dev: bad argument");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    hipError_t e = rtk_trace_any(s->view, d_rays, nullptr, d_tmax, n, s->eps_f, d_occ, (hipStream_t)stream);
+    if (e != hipSuccess) return rt_hipfail(e, "k_trace_any");
+    return RT_OK;
+}
+
+int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, uint8_t* occluded) {
+    if (!s || n < 0 || (n > 0 && (!rays || !occluded))) return rt_fail(RT_E_INVALID, "rt_trace_any: bad argument");
+    if (n == 0) return RT_OK;
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    void *dr, *dt = nullptr, *dout; int rc;
+    if ((rc = s->scratch(0, (size_t)n * sizeof(rt_ray), &dr))) return rc;
+    if ((rc = s->scratch(1, (size_t)n, &dout))) return rc;
+    hipError_t e = hipMemcpy(dr, rays, (size_t)n * sizeof(rt_ray), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(rays)");
+    if (tmax) {
+        if ((rc = s->scratch(2, (size_t)n * sizeof(float), &dt))) return rc;
+        e = hipMemcpy(dt, tmax, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(tmax)");
+    }
+    e = rtk_trace_any(s->view, (const rt_ray*)dr, nullptr, (const float*)dt, n, s->eps_f, (uint8_t*)dout, nullptr);
+    if (e != hipSuccess) return rt_hipfail(e, "k_trace_any");
+    e = hipMemcpy(occluded, dout, (size_t)n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(occluded)");
+    return RT_OK;
+}
+
+int rt_generate_primary_dev(rt_scene* s, const rt_camera* cam, int64_t first, int64_t n, float ox, float oy,
+                            rt_ray* d_rays, void* stream) {
+    if (!s || !cam || n < 0 || first < 0 || (n > 0 && !d_rays)) return rt_fail(RT_E_INVALID, "rt_generate_primary_dev: bad argument");
+    if (cam->resx <= 0 || cam->resy <= 0 || first + n > (int64_t)cam->resx * cam->resy)
+        return rt_fail(RT_E_INVALID, "rt_generate_primary_dev: pixel range outside the frame");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    hipError_t e = rtk_generate_linear(*cam, first, n, ox, oy, d_rays, (hipStream_t)stream);
+    if (e != hipSuccess) return rt_hipfail(e, "k_generate_linear");
+    return RT_OK;
+}
+
+}  // extern "C"
+
+// ---- host-only flatten (checks of the KD builder without a GPU) ------------
+struct rt_host_flat { HostFlatScene flat; };
+
+extern "C" int rt_host_flatten(const rt_scene_desc* d, rt_host_flat** out, rt_scene_info* info) {
+    if (!d || !out) return rt_fail(RT_E_INVALID, "rt_host_flatten: NULL argument");
+    *out = nullptr;
+    if (d->nprim < 0 || d->nmaterial <= 0 || !d->materials || (d->nprim > 0 && (!d->prims || !d->prim_type || !d->prim_material)))
+        return rt_fail(RT_E_INVALID, "rt_host_flatten: bad description");
+    rt_host_flat* f = new (std::nothrow) rt_host_flat();
+    if (!f) return rt_fail(RT_E_NOMEM, "host allocation failed");
+    std::string err;
+    int rc = rt_build_flat_scene(d, &f->flat, &err);
+    if (rc) { delete f; return rt_fail(rc, "%s", err.c_str()); }
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->kd_nodes_built = f->flat.kd_nodes_built; info->kd_max_depth = f->flat.kd_max_depth;
+        info->flat_nodes = (int64_t)f->flat.nodes.size(); info->leaf_refs = (int64_t)f->flat.leaf_tris.size();
+        info->ntri = f->flat.ntri; info->nsphere = f->flat.nsphere; info->nloose = (int64_t)f->flat.loose.size();
+    }
+    *out = f;
+    return RT_OK;
+}
+
+extern "C" int64_t rt_host_flat_get(const rt_host_flat* f, int which, void* dst, int64_t cap) {
+    if (!f) return rt_fail(RT_E_INVALID, "rt_host_flat_get: NULL");
+    const HostFlatScene& h = f->flat;
+    const int64_t nn = (int64_t)h.nodes.size(), nl = (int64_t)h.leaf_tris.size(), no = (int64_t)h.loose.size();
+    const int64_t rows = which <= 4 ? nn : (which == 6 ? no : nl);
+    if (which < 0 || which > 7) return rt_fail(RT_E_INVALID, "rt_host_flat_get: bad selector");
+    if (!dst) return rows;
+    if (cap < rows) return rt_fail(RT_E_INVALID, "rt_host_flat_get: buffer too small");
+    for (int64_t i = 0; i < rows; ++i) {
+        switch (which) {
+            case 0: memcpy((float*)dst + 6 * i, h.nodes[(size_t)i].lo, 24); break;
+            case 1: ((int32_t*)dst)[i] = h.nodes[(size_t)i].skip; break;
+            case 2: ((int32_t*)dst)[i] = h.nodes[(size_t)i].meta; break;
+            case 3: ((int32_t*)dst)[i] = h.leaf_range[(size_t)i].first; break;
+            case 4: ((int32_t*)dst)[i] = h.leaf_range[(size_t)i].count; break;
+            case 5: ((int32_t*)dst)[i] = h.leaf_tris[(size_t)i].prim; break;
+            case 6: ((int32_t*)dst)[i] = h.loose[(size_t)i].prim; break;
+            case 7: memcpy((float*)dst + 9 * i, h.leaf_tris[(size_t)i].v0, 36); break;
+        }
+    }
+    return rows;
+}
+
+extern "C" void rt_host_flat_free(rt_host_flat* f) { delete f; }

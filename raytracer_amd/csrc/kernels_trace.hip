@@ -1,0 +1,320 @@
+// kernels_trace.hip -- gfx950 traversal / intersection kernels of librt_hip.so.
+//
+// Replaces (paths under the reference root):
+//   KDNode::HitTest                 HW4/hw4/hw4.cpp:281-328
+//   Triangle::IntersectionTest      HW4/hw4/hw4.cpp:171-231 (non-culling branch)
+//   Sphere::IntersectionTest        HW4/hw4/hw4.cpp:73-116
+//   closest-hit loop                HW4/hw4/hw4.cpp:808-871, Final/photon/final.cpp:802-816
+//   any-hit loop (IsInShadow)       HW4/hw4/hw4.cpp:987-1046, Final/photon/final.cpp:997-1012
+//   GetPixelCenter + normalize      HW4/hw4/hw4.cpp:268-276,1053-1056
+//
+// Design (MI355X): the reference traversal is EXHAUSTIVE and its visit order
+// does not depend on the ray (pre-order, right child first, objects in file
+// order; a ray only filters that order through its box tests).  So one
+// 64-lane wavefront walks the node array front to back ONCE for its 64 rays:
+// the node / triangle records are wave-uniform (scalar-path loads, one fetch
+// per wave instead of 64), a wave-wide ballot decides whether a subtree is
+// entered, and each lane keeps a single integer (the depth at which it left
+// the current path) instead of a stack.  Per-lane results are bit-identical to
+// the reference because every lane performs exactly the reference's float
+// operations in the reference's order on the nodes the reference would visit.
+//
+// Compile with -ffp-contract=off and correctly rounded f32 divide / sqrt.
+#include <hip/hip_runtime.h>
+#include "rt_internal.h"
+
+#define RT_ALIVE 0x7fffffff
+#define RT_DEAD  (-1)
+
+namespace {
+
+struct Rayf { float ox, oy, oz, dx, dy, dz; };
+
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+
+// KDNode::HitTest, hw4.cpp:281-328.  lo/hi are center -/+ extend/2.0f.
+__device__ __forceinline__ bool box_test(const DevNode& n, const Rayf& r) {
+    float tmin = (n.lo[0] - r.ox) / r.dx;
+    float tmax = (n.hi[0] - r.ox) / r.dx;
+    if (tmin > tmax) { float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (n.lo[1] - r.oy) / r.dy;
+    float tymax = (n.hi[1] - r.oy) / r.dy;
+    if (tymin > tymax) { float t = tymin; tymin = tymax; tymax = t; }
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (n.lo[2] - r.oz) / r.dz;
+    float tzmax = (n.hi[2] - r.oz) / r.dz;
+    if (tzmin > tzmax) { float t = tzmin; tzmin = tzmax; tzmax = t; }
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    return true;
+}
+
+// Triangle::IntersectionTest, hw4.cpp:171-231.  a = {v0, edge1, edge2}.
+// eps_f = smallest float above the reference's double `epsilon` 1e-6, so
+// (det > -epsilon && det < epsilon) in double  <=>  |det| < eps_f in float.
+__device__ __forceinline__ bool tri_test(const float* __restrict__ a, const Rayf& r, float eps_f,
+                                         float& px, float& py, float& pz) {
+    const float v0x = a[0], v0y = a[1], v0z = a[2];
+    const float e1x = a[3], e1y = a[4], e1z = a[5];
+    const float e2x = a[6], e2y = a[7], e2z = a[8];
+    // pvec = rayDir ^ edge2
+    const float pvx = r.dy * e2z - r.dz * e2y;
+    const float pvy = r.dz * e2x - r.dx * e2z;
+    const float pvz = r.dx * e2y - r.dy * e2x;
+    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+    if (__builtin_fabsf(det) < eps_f) return false;
+    const float detInv = 1.0f / det;
+    const float tx = r.ox - v0x, ty = r.oy - v0y, tz = r.oz - v0z;
+    const float u = (tx * pvx + ty * pvy + tz * pvz) * detInv;
+    if (u < 0 || u > 1.0f) return false;
+    // qvec = tvec ^ edge1
+    const float qx = ty * e1z - tz * e1y;
+    const float qy = tz * e1x - tx * e1z;
+    const float qz = tx * e1y - ty * e1x;
+    const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * detInv;
+    if (v < 0 || u + v > 1.0f) return false;
+    const float t = (e2x * qx + e2y * qy + e2z * qz) * detInv;
+    if (t < 0) return false;
+    px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
+    return true;
+}
+
+// Sphere::IntersectionTest, hw4.cpp:73-116.  a = {center, radius}.
+__device__ __forceinline__ bool sphere_test(const float* __restrict__ a, const Rayf& r,
+                                            float& px, float& py, float& pz) {
+    const float hx = a[0] - r.ox, hy = a[1] - r.oy, hz = a[2] - r.oz;
+    const float mu = hx * r.dx + hy * r.dy + hz * r.dz;
+    const float delta = (mu * mu) - (hx * hx + hy * hy + hz * hz) + (a[3] * a[3]);
+    if (delta < 0) return false;
+    const float sq = sqrt_rn(delta);
+    const float t1 = mu + sq, t2 = mu - sq;
+    if (t1 <= 0 && t2 <= 0) return false;
+    float t;
+    if (t1 >= 0 && t2 < 0) t = t1;
+    else if (t1 < 0 && t2 >= 0) t = t2;
+    else t = t1 < t2 ? t1 : t2;
+    px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
+    return true;
+}
+
+// len = (ori - v).length(), hw4.cpp:851
+__device__ __forceinline__ float dist_to(const Rayf& r, float px, float py, float pz) {
+    const float ax = r.ox - px, ay = r.oy - py, az = r.oz - pz;
+    return sqrt_rn(ax * ax + ay * ay + az * az);
+}
+
+// vec3::normalize, algebra3.cpp:280-282,301: d_inv = 1./length (double divide)
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+    const float len = sqrt_rn(x * x + y * y + z * z);
+    const float di = (float)(1.0 / (double)len);
+    x *= di; y *= di; z *= di;
+}
+
+// culling term of hw4.cpp:853 / final.cpp:808: GetNormal(v) * dir < 0
+__device__ __forceinline__ bool facing(const DevSceneView& sc, int prim, bool sphere, const Rayf& r,
+                                       float px, float py, float pz) {
+    float nx, ny, nz;
+    if (sphere) {
+        const float* g = sc.prim_geom + 4 * (size_t)prim;
+        nx = px - g[0]; ny = py - g[1]; nz = pz - g[2];
+        normalize3(nx, ny, nz);
+    } else {
+        const float* n = sc.prim_normal + 3 * (size_t)prim;
+        nx = n[0]; ny = n[1]; nz = n[2];
+    }
+    return (nx * r.dx + ny * r.dy + nz * r.dz) < 0;
+}
+
+struct Closest { float len; int prim; float px, py, pz; };
+
+// One wave = 64 rays.  ANY: stop at the first accepted hit per lane.
+template <bool ANY>
+__device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, bool valid,
+                                         float eps_f, float tmax, bool use_tmax,
+                                         Closest& best, bool& occluded) {
+    int fail = valid ? RT_ALIVE : RT_DEAD;
+    const int nn = sc.nnodes;
+    int i = 0;
+    while (i < nn) {
+        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
+        const DevNode nd = sc.nodes[i];                 // wave-uniform address
+        const int depth = nd.meta & 0xff;
+        if (fail >= depth) fail = RT_ALIVE;             // left the subtree this lane had failed in
+        bool hit = false;
+        if (fail == RT_ALIVE) {
+            hit = box_test(nd, r);
+            if (!hit) fail = depth;
+        }
+        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
+        if (nd.meta & 0x100) {
+            const DevLeafRange lr = sc.leaf_range[i];
+            for (int k = 0; k < lr.count; ++k) {
+                const DevLeafTri* __restrict__ t = sc.leaf_tris + (lr.first + k);   // wave-uniform
+                if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+                if (hit) {
+                    float px, py, pz;
+                    if (tri_test(t->v0, r, eps_f, px, py, pz)) {
+                        const float len = dist_to(r, px, py, pz);
+                        if (ANY) {
+                            if (len < (use_tmax ? tmax : 1e9f) && len >= sc.tol_f) { occluded = true; fail = RT_DEAD; hit = false; }
+                        } else {
+                            if (len < best.len && len >= sc.tol_f &&
+                                (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
+                                best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        i = i + 1;
+    }
+    // primitives outside every tree, in index order (the whole scene for final.cpp)
+    bool live = valid && !(ANY && occluded);
+    for (int k = 0; k < sc.nloose; ++k) {
+        if (ANY) { if (__ballot(live) == 0ull) break; }
+        const DevLoose* __restrict__ l = sc.loose + k;                              // wave-uniform
+        const int flags = l->flags;
+        if (ANY && use_tmax && (flags & RT_PF_SKIP_SHADOW)) continue;
+        if (!live) continue;
+        float px, py, pz;
+        const bool sph = (flags & RT_PF_SPHERE) != 0;
+        const bool b = sph ? sphere_test(l->a, r, px, py, pz) : tri_test(l->a, r, eps_f, px, py, pz);
+        if (!b) continue;
+        const float len = dist_to(r, px, py, pz);
+        if (ANY) {
+            if (len < (use_tmax ? tmax : 1e9f) && len >= sc.tol_f) { occluded = true; live = false; }
+        } else {
+            if (len < best.len && len >= sc.tol_f && (!sc.culling || facing(sc, l->prim, sph, r, px, py, pz))) {
+                best.len = len; best.prim = l->prim; best.px = px; best.py = py; best.pz = pz;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ Rayf load_ray(const rt_ray* __restrict__ rays, int64_t i) {
+    const float* p = reinterpret_cast<const float*>(rays + i);
+    Rayf r; r.ox = p[0]; r.oy = p[1]; r.oz = p[2]; r.dx = p[3]; r.dy = p[4]; r.dz = p[5];
+    return r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// active: optional per-ray int32 (ray skipped when < 0), used by the renderer
+extern "C" __global__ void __launch_bounds__(256)
+k_trace_closest(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                int64_t n, float eps_f, rt_hit* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    const bool valid = inb && (active == nullptr || active[i] >= 0);
+    Rayf r = {0, 0, 0, 0, 0, 1};
+    if (valid) r = load_ray(rays, i);
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f;
+    bool occ = false;
+    traverse<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
+    if (inb) {
+        float* o = reinterpret_cast<float*>(out + i);
+        reinterpret_cast<int32_t*>(o)[0] = best.prim;
+        o[1] = best.len; o[2] = best.px; o[3] = best.py; o[4] = best.pz;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_trace_any(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+            const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    const bool valid = inb && (active == nullptr || active[i] >= 0);
+    Rayf r = {0, 0, 0, 0, 0, 1};
+    float tm = 0.f;
+    if (valid) { r = load_ray(rays, i); if (tmax) tm = tmax[i]; }
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f;
+    bool occ = false;
+    traverse<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
+    if (inb) occluded[i] = occ ? 1 : 0;
+}
+
+// Camera::GetPixelCenter + normalize, hw4.cpp:268-276, 1053-1056.
+__device__ __forceinline__ void primary_ray(const rt_camera& cam, float fx, float fy, float* o6) {
+    const float wx = cam.corners[1][0] - cam.corners[0][0], wy = cam.corners[1][1] - cam.corners[0][1],
+                wz = cam.corners[1][2] - cam.corners[0][2];
+    const float hx = cam.corners[0][0] - cam.corners[2][0], hy = cam.corners[0][1] - cam.corners[2][1],
+                hz = cam.corners[0][2] - cam.corners[2][2];
+    const float pixelWidth = sqrt_rn(wx * wx + wy * wy + wz * wz) / ((float)cam.resx);
+    const float pixelHeight = sqrt_rn(hx * hx + hy * hy + hz * hz) / ((float)cam.resy);
+    const float a = 0.5f * pixelWidth, b = 0.5f * pixelHeight, c = fx * pixelWidth, d = fy * pixelHeight;
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        p[k] = (((cam.corners[0][k] + a * cam.xaxis[k]) + b * cam.yaxis[k]) + c * cam.xaxis[k]) + d * cam.yaxis[k];
+    float dx = p[0] - cam.center[0], dy = p[1] - cam.center[1], dz = p[2] - cam.center[2];
+    normalize3(dx, dy, dz);
+    o6[0] = cam.center[0]; o6[1] = cam.center[1]; o6[2] = cam.center[2];
+    o6[3] = dx; o6[4] = dy; o6[5] = dz;
+}
+
+// rays in the reference's loop order: index = x*resy + y (hw4.cpp:1096-1098)
+extern "C" __global__ void __launch_bounds__(256)
+k_generate_linear(rt_camera cam, int64_t first, int64_t n, float ox, float oy, rt_ray* __restrict__ rays) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t g = first + i;
+    const int x = (int)(g / cam.resy), y = (int)(g % cam.resy);
+    primary_ray(cam, (float)x + ox, (float)y + oy, reinterpret_cast<float*>(rays + i));
+}
+
+// rays in wave-tile order: ray i belongs to micro-tile tiles[i/64] (8x8 pixels,
+// micro-tiles numbered row-major over ceil(resx/8) x ceil(resy/8)), lane i%64 is
+// pixel (lane%8, lane/8) of it.  pix[i] = x + y*resx, or -1 outside the frame.
+extern "C" __global__ void __launch_bounds__(256)
+k_generate_tiled(rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntiles, float ox, float oy,
+                 rt_ray* __restrict__ rays, int32_t* __restrict__ pix) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntiles * 64) return;
+    const int lane = (int)(i & 63);
+    const int t = tiles ? tiles[i >> 6] : (int)(i >> 6);
+    const int tw = (cam.resx + 7) >> 3;
+    const int x = (t % tw) * 8 + (lane & 7), y = (t / tw) * 8 + (lane >> 3);
+    float* o = reinterpret_cast<float*>(rays + i);
+    if (x >= cam.resx || y >= cam.resy) {
+        pix[i] = -1; o[0] = o[1] = o[2] = o[3] = o[4] = 0.f; o[5] = 1.f;
+        return;
+    }
+    pix[i] = x + y * cam.resx;
+    primary_ray(cam, (float)x + ox, (float)y + oy, o);
+}
+
+// ---------------------------------------------------------------------------
+// host launchers (declared in rt_internal.h)
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
+                             float eps_f, rt_hit* d_out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
+    return hipGetLastError();
+}
+
+hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
+                         int64_t n, float eps_f, uint8_t* d_occ, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+    return hipGetLastError();
+}
+
+hipError_t rtk_generate_linear(const rt_camera& cam, int64_t first, int64_t n, float ox, float oy, rt_ray* d_rays,
+                               hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_generate_linear, dim3(grid_for(n, 256)), dim3(256), 0, st, cam, first, n, ox, oy, d_rays);
+    return hipGetLastError();
+}
+
+hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float ox, float oy,
+                              rt_ray* d_rays, int32_t* d_pix, hipStream_t st) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_generate_tiled, dim3(grid_for(ntiles * 64, 256)), dim3(256), 0, st, cam, d_tiles, ntiles, ox,
+                       oy, d_rays, d_pix);
+    return hipGetLastError();
+}

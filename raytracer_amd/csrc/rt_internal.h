@@ -1,0 +1,119 @@
+// rt_internal.h -- shared between the host side (scene_build.cpp, api.cpp) and
+// the HIP kernels (kernels.hip) of librt_hip.so.  Not part of the ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/rt_hip.h"
+
+// ---------------------------------------------------------------------------
+// Device data layout (all arrays live in HBM, uploaded once per scene)
+//
+// KD nodes of ALL objects are stored in one array in the order the reference's
+// traversal pops them: pre-order with the RIGHT child first (hw4.cpp:831-836
+// pushes left then right, so right is popped first), objects in file order
+// (hw4.cpp:808).  Every record carries the index to continue at when its
+// subtree is skipped, so a wave walks the array front to back without a stack.
+struct DevNode {            // 32 B, fetched wave-uniformly (scalar path)
+    float lo[3];            // center - extend/2.0f  (hw4.cpp:287, precomputed with the same float ops)
+    float hi[3];            // center + extend/2.0f
+    int32_t skip;           // next node when this subtree is not entered (== index+1 for a leaf)
+    int32_t meta;           // bits 0..7 depth, bit 8 leaf
+};
+static_assert(sizeof(DevNode) == 32, "DevNode must be 32 bytes");
+
+struct DevLeafRange { int32_t first; int32_t count; };   // into leaf_tris; read only at leaves
+
+// One triangle reference of a leaf, stored in leaf order (a triangle that is
+// in several leaves is stored several times), so a leaf is one contiguous run.
+struct DevLeafTri {         // 48 B
+    float v0[3];            // vertices[0]
+    float e1[3];            // vertices[1]-vertices[0]   (hw4.cpp:177, same float op precomputed)
+    float e2[3];            // vertices[2]-vertices[0]   (hw4.cpp:178)
+    int32_t prim;           // scene-file index
+    int32_t flags;          // bit0: material refract > 0.1 (final.cpp:999)
+    int32_t pad;
+};
+static_assert(sizeof(DevLeafTri) == 48, "DevLeafTri must be 48 bytes");
+
+#define RT_PF_SKIP_SHADOW 1   // refract > 0.1
+#define RT_PF_SPHERE      2
+
+struct DevLoose {           // 48 B: a primitive tested one by one after the trees
+    float a[9];             // triangle: v0,e1,e2   sphere: center(3), radius, unused
+    int32_t prim;
+    int32_t flags;          // RT_PF_*
+    int32_t pad;
+};
+static_assert(sizeof(DevLoose) == 48, "DevLoose must be 48 bytes");
+
+struct DevMaterial {        // 48 B
+    float surf[3];
+    float Ka, Kd, Ks, specularity, reflect, refract, Nr;
+    float pad[2];
+};
+
+struct DevLight {           // 64 B
+    float pos[3]; float intensity;
+    float color[3]; int32_t type;
+    float dir1[3]; float size1;
+    float dir2[3]; float size2;
+};
+
+struct DevPhoton {          // 32 B, heap order (1-based; slot 0 unused)
+    float pos[3];
+    uint32_t packed;        // plane (bits 0..1) | theta<<8 | phi<<16
+    float power[3];
+    uint32_t pad;
+};
+static_assert(sizeof(DevPhoton) == 32, "DevPhoton must be 32 bytes");
+
+struct DevSceneView {       // passed by value to kernels
+    const DevNode* nodes; int32_t nnodes;
+    const DevLeafRange* leaf_range;
+    const DevLeafTri* leaf_tris;
+    const DevLoose* loose; int32_t nloose;
+    const float* prim_normal;   // [nprim][3] fixed-point normal (triangles)
+    const int32_t* prim_material;
+    const uint8_t* prim_type;
+    const float* prim_geom;     // [nprim][4] sphere centre+radius (spheres only)
+    const DevMaterial* materials;
+    const DevLight* lights; int32_t nlights;
+    float tol_f;                // smallest float t with (double)t > tolerance_depth  <=>  len >= tol_f
+    int32_t culling;
+    float shadow_bias, refract_bias;
+};
+
+// ---------------------------------------------------------------------------
+// host-side flattened scene produced by scene_build.cpp
+struct HostFlatScene {
+    std::vector<DevNode> nodes;
+    std::vector<DevLeafRange> leaf_range;
+    std::vector<DevLeafTri> leaf_tris;
+    std::vector<DevLoose> loose;
+    std::vector<float> prim_normal;
+    std::vector<float> prim_geom;
+    int64_t kd_nodes_built = 0;
+    int32_t kd_max_depth = 0;
+    int64_t ntri = 0, nsphere = 0;
+};
+
+// scene_build.cpp
+int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string* err);
+// photon_build.cpp
+void rt_photon_balance_host(rt_photon* photons, int64_t n);
+
+// smallest float f such that (double)f > t   (so  (double)x > t  <=>  x >= f  for every float x)
+float rt_float_above(double t);
+
+// ---------------------------------------------------------------------------
+// kernel launchers (defined in the .hip files)
+#include <hip/hip_runtime_api.h>
+hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
+                             float eps_f, rt_hit* d_out, hipStream_t st);
+hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
+                         int64_t n, float eps_f, uint8_t* d_occ, hipStream_t st);
+hipError_t rtk_generate_linear(const rt_camera& cam, int64_t first, int64_t n, float ox, float oy, rt_ray* d_rays,
+                               hipStream_t st);
+hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float ox, float oy,
+                              rt_ray* d_rays, int32_t* d_pix, hipStream_t st);

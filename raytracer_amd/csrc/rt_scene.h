@@ -1,0 +1,38 @@
+// rt_scene.h -- the opaque rt_scene of include/rt_hip.h (host side only).
+#pragma once
+#include "rt_internal.h"
+#include <hip/hip_runtime_api.h>
+
+#define RT_NSCRATCH 24
+
+struct DeviceGuard {
+    int prev, cur = -1; bool ok;
+    explicit DeviceGuard(int dev);
+    ~DeviceGuard();
+};
+
+struct PhotonMapDev {
+    DevPhoton* d_photons = nullptr;   // [n+1], heap order, slot 0 unused
+    int64_t n = 0;
+    int64_t half = 0;                 // half_stored_photons = n/2 - 1 (photon.cpp:168)
+};
+
+struct rt_scene {
+    int device = 0;
+    int64_t nprim = 0;
+    DevSceneView view;
+    float eps_f = 0.f;
+    rt_scene_info info;
+    std::vector<rt_light> host_lights;
+    std::vector<void*> allocs;
+    int64_t device_bytes = 0;
+    void* scratch_ptr[RT_NSCRATCH] = {};
+    size_t scratch_cap[RT_NSCRATCH] = {};
+    PhotonMapDev pmap[2];
+
+    int dev_alloc(void** p, size_t bytes);
+    int scratch(int slot, size_t bytes, void** p);
+};
+
+int rt_fail(int code, const char* fmt, ...);
+int rt_hipfail(hipError_t e, const char* what);

@@ -1,0 +1,171 @@
+"""Host-side handles over the C ABI (include/rt_hip.h, include/rt_host.h).
+
+`Scene` owns an `rt_scene*`; its methods have the names and argument meaning of
+the reference functions they replace (SimpleMeshRayTrace's closest-hit loop ->
+trace_closest, IsInShadow -> trace_any, CalcIrradiance -> photon_irradiance,
+GenerateColorImage -> render).  Everything computes on the GPU through
+librt_hip.so; nothing here falls back to the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .scene import SceneData
+
+_HOSTLIB = None
+
+
+def host_lib():
+    global _HOSTLIB
+    if _HOSTLIB is None:
+        p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_host.so")
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: build it with `make -C raytracer_amd/host`")
+        L = C.CDLL(p)
+        L.rth_camera_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.POINTER(abi.rt_camera)]
+        L.rth_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.rth_write_execution_time.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int64,
+                                               C.c_int32, C.c_double]
+        L.rth_ssaa_downsample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        _HOSTLIB = L
+    return _HOSTLIB
+
+
+def camera_setup(eye, view_raw, fov, resx, resy):
+    """Camera::CalcPlaneParameters (hw4.cpp:242-266) -> rt_camera."""
+    cam = abi.rt_camera()
+    e = np.ascontiguousarray(eye, np.float32); v = np.ascontiguousarray(view_raw, np.float32)
+    rc = host_lib().rth_camera_setup(e.ctypes.data, v.ctypes.data, float(fov), int(resx), int(resy), C.byref(cam))
+    if rc:
+        raise ValueError("rth_camera_setup: bad argument")
+    return cam
+
+
+def camera_for(sd: SceneData, resolution=None):
+    rx, ry = resolution if resolution else (sd.resx, sd.resy)
+    return camera_setup(sd.eye, sd.view, sd.fov, rx, ry)
+
+
+def write_ppm(path, rgb8, resx, resy):
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    if host_lib().rth_write_ppm(os.fsencode(path), a.ctypes.data, resx, resy):
+        raise OSError(f"cannot write {path}")
+
+
+def default_params(flavour="hw4", **kw):
+    p = abi.rt_params()
+    p.mode = abi.RT_RENDER_WHITTED if flavour == "hw4" else abi.RT_RENDER_PHOTON
+    p.max_depth = 10 if flavour == "hw4" else 5
+    p.ambient_intensity = 1.0
+    p.background[:] = [0.0, 0.0, 0.0]
+    p.start_nr = 1.0 if flavour == "hw4" else 2.4
+    p.primary_only = 0
+    p.tile_size = 0; p.tile_rank = 0; p.tile_nranks = 1
+    p.gather_samples = 50; p.knn_k = 100; p.knn_radius_global = 1.0; p.knn_radius_caustic = 0.1
+    p.irradiance_max_depth = 3; p.aa_taps = 0 if flavour == "hw4" else 6
+    p.seed = 1
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def host_flatten(sd: SceneData):
+    """The KD-trees exactly as rt_scene_create uploads them, built on the host (no GPU)."""
+    L = abi.load()
+    d, keep = sd.make_desc()
+    h = C.c_void_p(); info = abi.rt_scene_info()
+    abi.check(L.rt_host_flatten(C.byref(d), C.byref(h), C.byref(info)))
+    try:
+        def get(which, dtype, cols):
+            n = L.rt_host_flat_get(h, which, None, 0)
+            abi.check(n)
+            a = np.zeros((n, cols) if cols > 1 else (n,), dtype)
+            abi.check(L.rt_host_flat_get(h, which, a.ctypes.data, n))
+            return a
+        out = dict(lohi=get(0, np.float32, 6), skip=get(1, np.int32, 1), meta=get(2, np.int32, 1),
+                   leaf_first=get(3, np.int32, 1), leaf_count=get(4, np.int32, 1), leaf_prim=get(5, np.int32, 1),
+                   loose=get(6, np.int32, 1), leaf_tri=get(7, np.float32, 9), info=info)
+    finally:
+        L.rt_host_flat_free(h)
+    return out
+
+
+class Scene:
+    """rt_scene handle (GPU).  Raises RtError when no gfx950 device is usable."""
+
+    def __init__(self, sd: SceneData, device=-1):
+        self.L = abi.load()
+        self.sd = sd
+        d, keep = sd.make_desc(device)
+        h = C.c_void_p()
+        abi.check(self.L.rt_scene_create(C.byref(d), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_scene_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        i = abi.rt_scene_info()
+        abi.check(self.L.rt_scene_info_get(self.h, C.byref(i)))
+        return i
+
+    # ---- host-buffer entry points ------------------------------------------
+    def trace_closest(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(rays.shape[0], abi.hit_dtype)
+        abi.check(self.L.rt_trace_closest(self.h, rays.ctypes.data, rays.shape[0], out.ctypes.data))
+        return out
+
+    def trace_any(self, rays, tmax=None):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros(rays.shape[0], np.uint8)
+        t = None if tmax is None else np.ascontiguousarray(tmax, np.float32)
+        abi.check(self.L.rt_trace_any(self.h, rays.ctypes.data, None if t is None else t.ctypes.data,
+                                      rays.shape[0], out.ctypes.data))
+        return out
+
+    def render(self, cam, params, want_ids=False):
+        n = cam.resx * cam.resy
+        rgb = np.zeros(n * 3, np.uint8)
+        ids = np.zeros(n, np.int32) if want_ids else None
+        st = abi.rt_stats()
+        abi.check(self.L.rt_render(self.h, C.byref(cam), C.byref(params), rgb.ctypes.data,
+                                   None if ids is None else ids.ctypes.data, C.byref(st)))
+        return rgb.reshape(cam.resy, cam.resx, 3), ids, st
+
+    def photonmap_upload(self, which, heap_order):
+        a = np.ascontiguousarray(heap_order)
+        assert a.dtype == abi.photon_dtype
+        abi.check(self.L.rt_photonmap_upload(self.h, which, a.ctypes.data, a.shape[0] - 1))
+
+    def photonmap_build(self, which, photons):
+        a = np.ascontiguousarray(photons)
+        assert a.dtype == abi.photon_dtype
+        abi.check(self.L.rt_photonmap_build(self.h, which, a.ctypes.data, a.shape[0] - 1))
+        return a
+
+    def photon_knn(self, which, pos, k, max_dist):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        q = pos.shape[0]
+        idx = np.zeros((q, k), np.int32); d2 = np.zeros((q, k), np.float32)
+        found = np.zeros(q, np.int32); r2 = np.zeros(q, np.float32)
+        abi.check(self.L.rt_photon_knn(self.h, which, pos.ctypes.data, q, k, float(max_dist), idx.ctypes.data,
+                                       d2.ctypes.data, found.ctypes.data, r2.ctypes.data))
+        return idx, d2, found, r2
+
+    def photon_irradiance(self, which, pos, nrm, k, max_dist):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+        rgb = np.zeros((pos.shape[0], 3), np.float32)
+        abi.check(self.L.rt_photon_irradiance(self.h, which, pos.ctypes.data, nrm.ctypes.data, pos.shape[0], k,
+                                              float(max_dist), rgb.ctypes.data))
+        return rgb
