@@ -1,0 +1,121 @@
+"""GPU parity: rt_trace_closest / rt_trace_any (HIP, through the C ABI) against the
+CPU oracle on the same rays.  Bar: bit-exact prim ids, len and hit point bits,
+occlusion flags (integer / IEEE-exact float work)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from raytracer_amd import host, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _primary_rays(sd, resx, resy, step=1):
+    cam = ol.oracle_camera(sd.eye, sd.view, sd.fov, resx, resy)
+    xs, ys = np.meshgrid(np.arange(0, resx, step), np.arange(0, resy, step), indexing="ij")
+    return ol.oracle_primary_rays(cam, xs.ravel(), ys.ravel())
+
+
+def _random_rays(n, seed, box=1.5):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-box, box, (n, 3)).astype(np.float32)
+    o[:, 2] = rng.uniform(-1.5, 2.0, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    return np.concatenate([o, d.astype(np.float32)], axis=1)
+
+
+def _edge_rays():
+    """axis-parallel rays (zero direction components -> inf/NaN slabs, hw4.cpp:287-324 has no guard),
+    rays starting on geometry, rays along the floor diagonal (shared triangle edge)."""
+    r = []
+    for o in ([0, 0, -1], [0.1, 0.2, -1], [0, -0.5, 0.5], [0.25, -0.5, 0.25], [0, 0.1, 0.9]):
+        for d in ([0, 0, 1], [0, 1, 0], [1, 0, 0], [0, -1, 0], [0, 0, -1], [0, 0.6, 0.8], [0.6, 0, 0.8], [0.6, 0.8, 0]):
+            r.append(o + d)
+    t = np.linspace(-0.5, 0.5, 41)
+    for a in t:                       # straight down onto the floor diagonal x == z - 0.5 ... and nearby
+        r.append([a, 1.0, a + 0.5, 0, -1, 0])
+        r.append([a, 1.0, a + 0.5, 1e-3, -1, 0])
+    return np.array(r, np.float32)
+
+
+def _assert_hits_equal(g, o):
+    assert np.array_equal(g["prim"], o["prim"]), f"prim ids differ at {np.flatnonzero(g['prim'] != o['prim'])[:10]}"
+    hit = o["prim"] >= 0
+    assert np.array_equal(g["len"][hit].view(np.uint32), o["len"][hit].view(np.uint32))
+    assert np.array_equal(g["p"][hit].view(np.uint32), o["p"][hit].view(np.uint32))
+    assert np.all(g["len"][~hit] == np.float32(1e9))
+
+
+@pytest.fixture(scope="module")
+def monkey(monkey_sd):
+    g = host.Scene(monkey_sd)
+    o = ol.OracleScene(monkey_sd)
+    yield g, o
+    g.close(); o.close()
+
+
+def test_scene_info_matches_reference_log(monkey):
+    g, o = monkey
+    gi, oi = g.info(), o.info()
+    assert (gi.kd_nodes_built, gi.kd_max_depth) == (138, 9)          # executionTime_monkey.txt:4-5
+    assert (gi.flat_nodes, gi.leaf_refs) == (oi.flat_nodes, oi.leaf_refs)
+
+
+def test_closest_primary_256(monkey, monkey_sd):
+    g, o = monkey
+    rays = _primary_rays(monkey_sd, 256, 256)
+    _assert_hits_equal(g.trace_closest(rays), o.trace_closest(rays))
+
+
+def test_closest_random_and_edge_rays(monkey):
+    g, o = monkey
+    rays = np.concatenate([_random_rays(20000, 7), _edge_rays()])
+    _assert_hits_equal(g.trace_closest(rays), o.trace_closest(rays))
+
+
+def test_closest_ragged_sizes(monkey):
+    g, o = monkey
+    base = _random_rays(300, 11)
+    for n in (0, 1, 63, 64, 65, 255, 257):
+        gh = g.trace_closest(base[:n]); oh = o.trace_closest(base[:n])
+        assert gh.shape[0] == n
+        if n:
+            _assert_hits_equal(gh, oh)
+
+
+def test_any_hit_hw4_semantics(monkey, monkey_sd):
+    """IsInShadow, hw4.cpp:957-1051: shadow rays from primary hit points to the light."""
+    g, o = monkey
+    rays = _primary_rays(monkey_sd, 128, 128)
+    hits = o.trace_closest(rays)
+    ok = hits["prim"] >= 0
+    p = hits["p"][ok]
+    light = np.array(monkey_sd.lights[0]["pos"], np.float32)
+    d = light - p
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    srays = np.concatenate([p + np.float32(1e-4) * d, d], axis=1).astype(np.float32)
+    srays = np.concatenate([srays, _random_rays(5000, 3)])
+    go, oo = g.trace_any(srays), o.trace_any(srays)
+    assert np.array_equal(go, oo)
+    assert 0 < oo.sum() < oo.size
+
+
+def test_any_hit_with_tmax(monkey):
+    """final.cpp:997-1012 semantics on the KD scene: len < tLight."""
+    g, o = monkey
+    rays = _random_rays(8000, 5)
+    tmax = np.random.default_rng(1).uniform(0.05, 2.0, rays.shape[0]).astype(np.float32)
+    assert np.array_equal(g.trace_any(rays, tmax), o.trace_any(rays, tmax))
+
+
+def test_final_scene_brute_force_with_spheres_and_culling():
+    """Final/photon scene: no KD-tree, spheres, culling on, TOLERANCE_DEPTH 1e-3 (final.cpp:802-816)."""
+    import os
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    g = host.Scene(sd); o = ol.OracleScene(sd)
+    rays = np.concatenate([_primary_rays(sd, 96, 96), _random_rays(6000, 9, box=0.45)])
+    _assert_hits_equal(g.trace_closest(rays), o.trace_closest(rays))
+    tmax = np.random.default_rng(2).uniform(0.05, 1.5, rays.shape[0]).astype(np.float32)
+    assert np.array_equal(g.trace_any(rays, tmax), o.trace_any(rays, tmax))
+    g.close(); o.close()
