@@ -1,0 +1,364 @@
+// kernels_shade.hip -- wavefront shading for the Whitted renderer.
+//
+// Replaces the shading block of SimpleMeshRayTrace (HW4/hw4/hw4.cpp:881-951)
+// and the per-pixel quantisation of GenerateColorImage (hw4.cpp:1108-1122).
+// The reference recurses (reflect, then refract, then local terms); here every
+// ray carries a scalar weight (the product of the reflect / refract factors
+// above it) and each pass of the wavefront handles one recursion depth:
+//
+//   trace_closest -> k_shade_flags  (normal, which children exist, shadow rays)
+//                 -> trace_any      (one shadow ray per hit and light)
+//                 -> k_shade_lights (ambient + Blinn-Phong, weight applied)
+//                 -> k_accumulate   (ordered per-pixel sum: deterministic)
+//                 -> scan + k_spawn (stable compaction of the children)
+//
+// Rays of one pixel stay contiguous and ordered through the stable compaction,
+// so the per-pixel sums are evaluated in a fixed order: the image does not
+// depend on how the frame is tiled over GPUs.
+#include <hip/hip_runtime.h>
+#include "rt_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {     // algebra3.cpp:280-282,301
+    const float len = sqrt_rn(x * x + y * y + z * z);
+    const float di = (float)(1.0 / (double)len);
+    x *= di; y *= di; z *= di;
+}
+__device__ __forceinline__ float max_std(float a, float b) { return (a < b) ? b : a; }   // std::max
+
+struct HitCtx {
+    float ox, oy, oz, dx, dy, dz;      // the ray
+    float hx, hy, hz;                  // hitPoint
+    float nx, ny, nz;                  // normal, flipped against the ray (hw4.cpp:888-891)
+    int prim, mat;
+};
+
+__device__ __forceinline__ bool load_hit(const DevSceneView& sc, const rt_ray* __restrict__ rays,
+                                         const rt_hit* __restrict__ hits, int64_t i, HitCtx& c) {
+    const float* h = reinterpret_cast<const float*>(hits + i);
+    c.prim = reinterpret_cast<const int32_t*>(h)[0];
+    if (c.prim < 0) return false;
+    c.hx = h[2]; c.hy = h[3]; c.hz = h[4];
+    const float* r = reinterpret_cast<const float*>(rays + i);
+    c.ox = r[0]; c.oy = r[1]; c.oz = r[2]; c.dx = r[3]; c.dy = r[4]; c.dz = r[5];
+    c.mat = sc.prim_material[c.prim];
+    if (sc.prim_type[c.prim] == RT_PRIM_SPHERE) {                 // Sphere::GetNormal, hw4.cpp:118-120
+        const float* g = sc.prim_geom + 4 * (size_t)c.prim;
+        c.nx = c.hx - g[0]; c.ny = c.hy - g[1]; c.nz = c.hz - g[2];
+        normalize3(c.nx, c.ny, c.nz);
+    } else {                                                      // Triangle::GetNormal, hw4.cpp:122-137
+        const float* n = sc.prim_normal + 3 * (size_t)c.prim;
+        c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
+    }
+    if (c.nx * c.dx + c.ny * c.dy + c.nz * c.dz > 0) { c.nx = -1.0f * c.nx; c.ny = -1.0f * c.ny; c.nz = -1.0f * c.nz; }
+    return true;
+}
+
+}  // namespace
+
+// counters[0]=valid rays in, [1]=hits, [2]=shadow rays, [3]=reflect children, [4]=refract children
+__device__ __forceinline__ void wave_count(unsigned long long* ctr, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
+}
+
+// Per traced ray: child flags (2 per ray), one biased shadow ray per light, and for the
+// primary pass the hit id / "rayHitAnything" image (hw4.cpp:883-884).
+extern "C" __global__ void __launch_bounds__(256)
+k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restrict__ hits,
+              const int32_t* __restrict__ pix, int64_t n, int spawn_children, int primary_pass,
+              uint8_t* __restrict__ child_flags, rt_ray* __restrict__ srays, int32_t* __restrict__ sactive,
+              int32_t* __restrict__ hit_ids, uint8_t* __restrict__ hit_any, unsigned long long* __restrict__ counters) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    const int px = inb ? pix[i] : -1;
+    HitCtx c;
+    const bool hit = (px >= 0) && load_hit(sc, rays, hits, i, c);
+    wave_count(counters + 0, px >= 0);
+    wave_count(counters + 1, hit);
+    if (!inb) return;
+    const int L = sc.nlights;
+    if (primary_pass && px >= 0) {
+        if (hit_ids) hit_ids[px] = hit ? c.prim : -1;
+        hit_any[px] = hit ? 1 : 0;
+    }
+    uint8_t f0 = 0, f1 = 0;
+    if (hit) {
+        const DevMaterial m = sc.materials[c.mat];
+        if (spawn_children) {
+            f0 = m.reflect > 0.0001f;                         // hw4.cpp:897
+            f1 = (double)m.refract > 0.0001;                  // hw4.cpp:907 (double literal)
+        }
+        // IsInShadow's ray, hw4.cpp:961-963
+        const float bx = c.hx + sc.shadow_bias * c.nx, by = c.hy + sc.shadow_bias * c.ny, bz = c.hz + sc.shadow_bias * c.nz;
+        for (int l = 0; l < L; ++l) {
+            const DevLight lt = sc.lights[l];
+            float dx = lt.pos[0] - bx, dy = lt.pos[1] - by, dz = lt.pos[2] - bz;
+            normalize3(dx, dy, dz);
+            float* o = reinterpret_cast<float*>(srays + (i * L + l));
+            o[0] = bx; o[1] = by; o[2] = bz; o[3] = dx; o[4] = dy; o[5] = dz;
+            sactive[i * L + l] = 0;
+        }
+    } else {
+        for (int l = 0; l < L; ++l) sactive[i * L + l] = -1;
+    }
+    if (child_flags) { child_flags[2 * i] = f0; child_flags[2 * i + 1] = f1; }
+}
+
+// ambient + per-light Blinn-Phong, hw4.cpp:926-948, including the reference's quirk that
+// `diffuse`/`specular` keep the previous light's values when a light is shadowed (:876-877,:947).
+extern "C" __global__ void __launch_bounds__(256)
+k_shade_lights(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restrict__ hits,
+               const int32_t* __restrict__ pix, const float* __restrict__ weight, int64_t n,
+               const uint8_t* __restrict__ occluded, float ambient_intensity, float eyex, float eyey, float eyez,
+               float* __restrict__ contrib, unsigned long long* __restrict__ counters) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    HitCtx c;
+    const bool hit = inb && pix[i] >= 0 && load_hit(sc, rays, hits, i, c);
+    {
+        const unsigned long long hm = __ballot(hit);
+        if (hm && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(hm))
+            atomicAdd(counters + 2, (unsigned long long)__builtin_popcountll(hm) * (unsigned long long)sc.nlights);
+    }
+    if (!inb) return;
+    if (hit) {
+        const DevMaterial m = sc.materials[c.mat];
+        // ambient = (surfColor * ambientIntensity) * Ka
+        cr = (ambient_intensity * m.surf[0]) * m.Ka; cg = (ambient_intensity * m.surf[1]) * m.Ka; cb = (ambient_intensity * m.surf[2]) * m.Ka;
+        float dr = 0, dg = 0, db = 0, sr = 0, sg = 0, sb = 0;
+        const int L = sc.nlights;
+        for (int l = 0; l < L; ++l) {
+            if (!occluded[i * L + l]) {
+                const DevLight lt = sc.lights[l];
+                float tx = lt.pos[0] - c.hx, ty = lt.pos[1] - c.hy, tz = lt.pos[2] - c.hz;
+                normalize3(tx, ty, tz);
+                float dot = max_std(tx * c.nx + ty * c.ny + tz * c.nz, 0.0f);
+                const float ir = lt.intensity * m.surf[0], ig = lt.intensity * m.surf[1], ib = lt.intensity * m.surf[2];
+                const float kd = m.Kd * dot;
+                dr = kd * ir; dg = kd * ig; db = kd * ib;
+                float ex = eyex - c.hx, ey = eyey - c.hy, ez = eyez - c.hz;
+                normalize3(ex, ey, ez);
+                float hx = ex + tx, hy = ey + ty, hz = ez + tz;
+                normalize3(hx, hy, hz);
+                dot = max_std(hx * c.nx + hy * c.ny + hz * c.nz, 0.0f);
+                const float pw = powf(dot, m.specularity);
+                sr = pw * (m.Ks * ir); sg = pw * (m.Ks * ig); sb = pw * (m.Ks * ib);
+            }
+            cr = (cr + dr) + sr; cg = (cg + dg) + sg; cb = (cb + db) + sb;
+        }
+        const float w = weight ? weight[i] : 1.0f;
+        cr *= w; cg *= w; cb *= w;
+    }
+    contrib[3 * i] = cr; contrib[3 * i + 1] = cg; contrib[3 * i + 2] = cb;
+}
+
+// Ordered per-pixel accumulation: the first ray of each run of equal pixel ids adds the run.
+extern "C" __global__ void __launch_bounds__(256)
+k_accumulate(const int32_t* __restrict__ pix, const float* __restrict__ contrib, int64_t n, float* __restrict__ accum) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix[i];
+    if (p < 0 || (i > 0 && pix[i - 1] == p)) return;
+    float r = accum[3 * (size_t)p], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
+    for (int64_t j = i; j < n && pix[j] == p; ++j) { r += contrib[3 * j]; g += contrib[3 * j + 1]; b += contrib[3 * j + 2]; }
+    accum[3 * (size_t)p] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
+}
+
+// ---- stable compaction of the children ------------------------------------
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+extern "C" __global__ void __launch_bounds__(SCAN_BLOCK)
+k_scan_count(const uint8_t* __restrict__ flags, int64_t n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t red[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) s += flags[base + k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += red[w]; block_sums[blockIdx.x] = t; }
+}
+
+// single block: exclusive scan of block_sums in place, total -> *total
+extern "C" __global__ void __launch_bounds__(1024)
+k_scan_blocks(uint32_t* __restrict__ block_sums, int64_t nblocks, uint32_t* __restrict__ total) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblocks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t t = threadIdx.x >= (unsigned)off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = buf[threadIdx.x];
+        if (i < nblocks) block_sums[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// Children of ray i: slot 2i = reflection (hw4.cpp:897-904), slot 2i+1 = refraction (:907-924).
+extern "C" __global__ void __launch_bounds__(SCAN_BLOCK)
+k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restrict__ hits,
+        const int32_t* __restrict__ pix, const float* __restrict__ weight, const float* __restrict__ nr_in,
+        const uint8_t* __restrict__ flags, int64_t nflags, const uint32_t* __restrict__ block_offsets,
+        rt_ray* __restrict__ orays, int32_t* __restrict__ opix, float* __restrict__ oweight, float* __restrict__ onr,
+        unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t wsum[SCAN_BLOCK / 64];
+    __shared__ unsigned int kinds[2];
+    if (threadIdx.x < 2) kinds[threadIdx.x] = 0;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint8_t f[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { f[k] = (base + k < nflags) ? flags[base + k] : 0; s += f[k]; }
+    // exclusive scan of s over the block
+    uint32_t incl = s;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+    uint32_t pos = block_offsets[blockIdx.x] + woff + incl - s;
+    int nrefl = 0, nrefr = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (!f[k]) continue;
+        const int64_t slot = base + k, i = slot >> 1;
+        HitCtx c;
+        load_hit(sc, rays, hits, i, c);
+        const DevMaterial m = sc.materials[c.mat];
+        const float w = weight ? weight[i] : 1.0f;
+        float* o = reinterpret_cast<float*>(orays + pos);
+        if ((slot & 1) == 0) {
+            const float dot = c.dx * c.nx + c.dy * c.ny + c.dz * c.nz;
+            const float k2 = 2 * dot;                                  // reflected = dir - 2*dot*normal
+            o[0] = c.hx; o[1] = c.hy; o[2] = c.hz;
+            o[3] = c.dx - k2 * c.nx; o[4] = c.dy - k2 * c.ny; o[5] = c.dz - k2 * c.nz;
+            oweight[pos] = w * m.reflect; onr[pos] = nr_in ? nr_in[i] : 1.0f;
+            ++nrefl;
+        } else {
+            const float n1 = nr_in ? nr_in[i] : 1.0f, n2 = m.Nr;
+            const float cos1 = c.dx * c.nx + c.dy * c.ny + c.dz * c.nz;
+            const float ratio = n1 / n2;
+            const float sin2 = ratio * sqrt_rn(1 - (cos1 * cos1));
+            const float kk = cos1 * ratio - sqrt_rn(1 - (sin2 * sin2));
+            float tx = ratio * c.dx + kk * c.nx, ty = ratio * c.dy + kk * c.ny, tz = ratio * c.dz + kk * c.nz;
+            normalize3(tx, ty, tz);
+            o[0] = c.hx - sc.refract_bias * c.nx; o[1] = c.hy - sc.refract_bias * c.ny; o[2] = c.hz - sc.refract_bias * c.nz;
+            o[3] = tx; o[4] = ty; o[5] = tz;
+            oweight[pos] = w * m.refract; onr[pos] = n2;
+            ++nrefr;
+        }
+        opix[pos] = pix[i];
+        ++pos;
+    }
+    if (nrefl) atomicAdd(&kinds[0], (unsigned)nrefl);
+    if (nrefr) atomicAdd(&kinds[1], (unsigned)nrefr);
+    __syncthreads();
+    if (threadIdx.x < 2 && kinds[threadIdx.x]) atomicAdd(counters + 3 + threadIdx.x, (unsigned long long)kinds[threadIdx.x]);
+}
+
+// GenerateColorImage's pixel write, hw4.cpp:1108-1122.  One thread per primary ray of this rank.
+__device__ __forceinline__ uint8_t quantize(float c) {
+    if (c > 1.0f) return 255;
+    const float v = c * 255.0f;
+    if (!(v > -2147483648.0f && v < 2147483648.0f)) return 0;     // cvttss2si's 0x80000000 -> low byte 0
+    return (uint8_t)(int32_t)v;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_finalize(const int32_t* __restrict__ pix0, int64_t n, const float* __restrict__ accum,
+           const uint8_t* __restrict__ hit_any, float bgr, float bgg, float bgb, uint8_t* __restrict__ rgb8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix0[i];
+    if (p < 0) return;
+    uint8_t* o = rgb8 + 3 * (size_t)p;
+    if (hit_any[p]) {
+        o[0] = quantize(accum[3 * (size_t)p]); o[1] = quantize(accum[3 * (size_t)p + 1]); o[2] = quantize(accum[3 * (size_t)p + 2]);
+    } else {
+        o[0] = (uint8_t)bgr; o[1] = (uint8_t)bgg; o[2] = (uint8_t)bgb;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_zero_pixels(const int32_t* __restrict__ pix0, int64_t n, float* __restrict__ accum) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix0[i];
+    if (p < 0) return;
+    accum[3 * (size_t)p] = 0.f; accum[3 * (size_t)p + 1] = 0.f; accum[3 * (size_t)p + 2] = 0.f;
+}
+
+// ---------------------------------------------------------------------------
+static inline unsigned gridf(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
+                           int spawn_children, int primary_pass, uint8_t* child_flags, rt_ray* srays, int32_t* sactive,
+                           int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_shade_flags, dim3(gridf(n, 256)), dim3(256), 0, st, sc, rays, hits, pix, n, spawn_children,
+                       primary_pass, child_flags, srays, sactive, hit_ids, hit_any, counters);
+    return hipGetLastError();
+}
+
+hipError_t rtk_shade_lights(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
+                            const float* weight, int64_t n, const uint8_t* occluded, float ambient, const float eye[3],
+                            float* contrib, unsigned long long* counters, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_shade_lights, dim3(gridf(n, 256)), dim3(256), 0, st, sc, rays, hits, pix, weight, n, occluded,
+                       ambient, eye[0], eye[1], eye[2], contrib, counters);
+    return hipGetLastError();
+}
+
+hipError_t rtk_accumulate(const int32_t* pix, const float* contrib, int64_t n, float* accum, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_accumulate, dim3(gridf(n, 256)), dim3(256), 0, st, pix, contrib, n, accum);
+    return hipGetLastError();
+}
+
+int64_t rtk_scan_blocks_needed(int64_t nflags) { return (nflags + SCAN_TILE - 1) / SCAN_TILE; }
+
+hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
+                                const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
+                                uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
+                                float* onr, unsigned long long* counters, hipStream_t st) {
+    if (nflags <= 0) return hipSuccess;
+    const int64_t nb = rtk_scan_blocks_needed(nflags);
+    hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, nflags, block_sums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, nb, d_total);
+    hipLaunchKernelGGL(k_spawn, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, sc, rays, hits, pix, weight, nr_in, flags,
+                       nflags, block_sums, orays, opix, oweight, onr, counters);
+    return hipGetLastError();
+}
+
+hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
+                        uint8_t* rgb8, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum, hit_any, bg[0], bg[1], bg[2], rgb8);
+    return hipGetLastError();
+}
+
+hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_pixels, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum);
+    return hipGetLastError();
+}

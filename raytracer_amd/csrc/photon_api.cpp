@@ -1,0 +1,156 @@
+// photon_api.cpp -- photon-map entry points of include/rt_hip.h: upload of a
+// balanced map (final.cpp:1125-1129 hands it to the renderer), host balance
+// (photon.cpp:133-254), kNN (photon.cpp:53-131) and irradiance (:342-443).
+#include "rt_scene.h"
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
+#define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+namespace {
+
+enum { S_Q_POS = 0, S_Q_NRM = 1, S_Q_IDX = 2, S_Q_D2 = 3, S_Q_FOUND = 4, S_Q_R2 = 5, S_Q_RGB = 6 };
+const int KNN_K_MAX = 287;       // (2(k+1)+64)*256 B of LDS must fit 160 KiB
+
+// InitDirectionTable, photon.cpp:40-50 (PI = 3.141592, parameter.h:6)
+int ensure_tables(rt_scene* s) {
+    if (s->d_dir_tables) return RT_OK;
+    float t[1024];
+    for (int i = 0; i < 256; ++i) {
+        const double angle = double(i) * (1.0 / 256.0) * 3.141592;
+        t[i] = (float)std::cos(angle); t[256 + i] = (float)std::sin(angle);
+        t[512 + i] = (float)std::cos(2.0 * angle); t[768 + i] = (float)std::sin(2.0 * angle);
+    }
+    void* p; RTCHK(s->dev_alloc(&p, sizeof t));
+    HIPCHK(hipMemcpy(p, t, sizeof t, hipMemcpyHostToDevice), "copy tables");
+    s->d_dir_tables = (float*)p;
+    return RT_OK;
+}
+
+int check_map(rt_scene* s, int which, int k, const char* fn) {
+    if (!s || which < 0 || which > 1) return rt_fail(RT_E_INVALID, "%s: bad scene or map selector", fn);
+    if (k < 1 || k > KNN_K_MAX) return rt_fail(RT_E_LIMIT, "%s: k=%d outside [1,%d]", fn, k, KNN_K_MAX);
+    if (!s->pmap[which].d_photons) return rt_fail(RT_E_STATE, "%s: photon map %d not uploaded", fn, which);
+    return RT_OK;
+}
+
+int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
+    PhotonMapDev& m = s->pmap[which];
+    if (m.d_photons) { (void)hipFree(m.d_photons); m.d_photons = nullptr; m.n = 0; }
+    std::vector<DevPhoton> dev;
+    try { dev.resize((size_t)n + 1); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
+    memset(dev.data(), 0, sizeof(DevPhoton));
+    for (int64_t i = 1; i <= n; ++i) {
+        const rt_photon& p = heap[i];
+        DevPhoton& d = dev[(size_t)i];
+        memcpy(d.pos, p.position, 12); memcpy(d.power, p.power, 12);
+        d.packed = ((uint32_t)p.plane & 3u) | ((uint32_t)p.theta << 8) | ((uint32_t)p.phi << 16);
+        d.pad = 0;
+    }
+    hipError_t e = hipMalloc((void**)&m.d_photons, dev.size() * sizeof(DevPhoton));
+    if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(photon map %zu B): %s", dev.size() * sizeof(DevPhoton), hipGetErrorString(e));
+    HIPCHK(hipMemcpy(m.d_photons, dev.data(), dev.size() * sizeof(DevPhoton), hipMemcpyHostToDevice), "copy photon map");
+    m.n = n;
+    m.half = n / 2 - 1;                       // photon.cpp:168
+    return ensure_tables(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_photonmap_upload(rt_scene* s, int which, const rt_photon* heap_order, int64_t n) {
+    if (!s || which < 0 || which > 1 || n < 0 || !heap_order) return rt_fail(RT_E_INVALID, "rt_photonmap_upload: bad argument");
+    if (n >= ((int64_t)1 << 31) - 2) return rt_fail(RT_E_LIMIT, "rt_photonmap_upload: more than 2^31 photons");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    return upload_heap(s, which, heap_order, n);
+}
+
+int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n) {
+    if (!s || which < 0 || which > 1 || n < 0 || !photons) return rt_fail(RT_E_INVALID, "rt_photonmap_build: bad argument");
+    if (n >= ((int64_t)1 << 31) - 2) return rt_fail(RT_E_LIMIT, "rt_photonmap_build: more than 2^31 photons");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    try { rt_photon_balance_host(photons, n); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
+    return upload_heap(s, which, photons, n);
+}
+
+int rt_photon_knn_dev(rt_scene* s, int which, const float* d_pos3, int64_t q, int k, float maxDist, int32_t* d_idx,
+                      float* d_dist2, int32_t* d_found, float* d_radius2, void* stream) {
+    RTCHK(check_map(s, which, k, "rt_photon_knn_dev"));
+    if (q < 0 || (q > 0 && (!d_pos3 || !d_idx || !d_dist2 || !d_found))) return rt_fail(RT_E_INVALID, "rt_photon_knn_dev: bad argument");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    const PhotonMapDev& m = s->pmap[which];
+    HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, d_pos3, nullptr, q, k, maxDist, 0, d_idx, d_dist2, d_found, d_radius2,
+                          nullptr, s->d_dir_tables, (hipStream_t)stream), "k_photon_knn");
+    return RT_OK;
+}
+
+int rt_photon_knn(rt_scene* s, int which, const float* pos3, int64_t q, int k, float maxDist, int32_t* idx, float* dist2,
+                  int32_t* found, float* radius2) {
+    RTCHK(check_map(s, which, k, "rt_photon_knn"));
+    if (q < 0 || (q > 0 && (!pos3 || !idx || !dist2 || !found))) return rt_fail(RT_E_INVALID, "rt_photon_knn: bad argument");
+    if (q == 0) return RT_OK;
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    void *dp, *di, *dd, *df, *dr;
+    RTCHK(s->scratch(S_Q_POS, (size_t)q * 12, &dp));
+    RTCHK(s->scratch(S_Q_IDX, (size_t)q * k * 4, &di));
+    RTCHK(s->scratch(S_Q_D2, (size_t)q * k * 4, &dd));
+    RTCHK(s->scratch(S_Q_FOUND, (size_t)q * 4, &df));
+    RTCHK(s->scratch(S_Q_R2, (size_t)q * 4, &dr));
+    HIPCHK(hipMemcpy(dp, pos3, (size_t)q * 12, hipMemcpyHostToDevice), "copy queries");
+    const PhotonMapDev& m = s->pmap[which];
+    HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, (const float*)dp, nullptr, q, k, maxDist, 0, (int32_t*)di, (float*)dd,
+                          (int32_t*)df, (float*)dr, nullptr, s->d_dir_tables, nullptr), "k_photon_knn");
+    HIPCHK(hipMemcpy(idx, di, (size_t)q * k * 4, hipMemcpyDeviceToHost), "copy idx");
+    HIPCHK(hipMemcpy(dist2, dd, (size_t)q * k * 4, hipMemcpyDeviceToHost), "copy dist2");
+    HIPCHK(hipMemcpy(found, df, (size_t)q * 4, hipMemcpyDeviceToHost), "copy found");
+    if (radius2) HIPCHK(hipMemcpy(radius2, dr, (size_t)q * 4, hipMemcpyDeviceToHost), "copy radius2");
+    return RT_OK;
+}
+
+int rt_photon_irradiance_dev(rt_scene* s, int which, const float* d_pos3, const float* d_nrm3, int64_t q, int k,
+                             float maxDist, float* d_rgb, void* stream) {
+    RTCHK(check_map(s, which, k, "rt_photon_irradiance_dev"));
+    if (q < 0 || (q > 0 && (!d_pos3 || !d_nrm3 || !d_rgb))) return rt_fail(RT_E_INVALID, "rt_photon_irradiance_dev: bad argument");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    const PhotonMapDev& m = s->pmap[which];
+    HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, d_pos3, d_nrm3, q, k, maxDist, 1, nullptr, nullptr, nullptr, nullptr,
+                          d_rgb, s->d_dir_tables, (hipStream_t)stream), "k_photon_knn");
+    return RT_OK;
+}
+
+int rt_photon_irradiance(rt_scene* s, int which, const float* pos3, const float* nrm3, int64_t q, int k, float maxDist,
+                         float* rgb) {
+    RTCHK(check_map(s, which, k, "rt_photon_irradiance"));
+    if (q < 0 || (q > 0 && (!pos3 || !nrm3 || !rgb))) return rt_fail(RT_E_INVALID, "rt_photon_irradiance: bad argument");
+    if (q == 0) return RT_OK;
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    void *dp, *dn, *dc;
+    RTCHK(s->scratch(S_Q_POS, (size_t)q * 12, &dp));
+    RTCHK(s->scratch(S_Q_NRM, (size_t)q * 12, &dn));
+    RTCHK(s->scratch(S_Q_RGB, (size_t)q * 12, &dc));
+    HIPCHK(hipMemcpy(dp, pos3, (size_t)q * 12, hipMemcpyHostToDevice), "copy queries");
+    HIPCHK(hipMemcpy(dn, nrm3, (size_t)q * 12, hipMemcpyHostToDevice), "copy normals");
+    const PhotonMapDev& m = s->pmap[which];
+    HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, (const float*)dp, (const float*)dn, q, k, maxDist, 1, nullptr, nullptr,
+                          nullptr, nullptr, (float*)dc, s->d_dir_tables, nullptr), "k_photon_knn");
+    HIPCHK(hipMemcpy(rgb, dc, (size_t)q * 12, hipMemcpyDeviceToHost), "copy rgb");
+    return RT_OK;
+}
+
+int rt_photonmap_emit(rt_scene* s, int which, int64_t first, int64_t count, uint64_t seed, rt_photon* out, int64_t cap,
+                      int64_t* nstored) {
+    (void)s; (void)which; (void)first; (void)count; (void)seed; (void)out; (void)cap; (void)nstored;
+    return rt_fail(RT_E_STATE, "rt_photonmap_emit: GPU photon emission is not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// render.cpp -- rt_render / rt_render_dev: the frame driver that replaces
+// GenerateColorImage (HW4/hw4/hw4.cpp:1081-1129) with a wavefront pipeline:
+// generate -> [trace_closest -> shade -> trace_any -> light -> accumulate ->
+// compact children]* -> quantise.  One pass per recursion depth of
+// SimpleMeshRayTrace (hw4.cpp:794-955; depth limit :796).
+#include "rt_scene.h"
+#include <cstring>
+#include <vector>
+
+namespace {
+
+enum Slot {   // scratch slots of rt_scene used by the renderer
+    S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
+    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS
+};
+static_assert(S_COUNTERS < RT_NSCRATCH, "not enough scratch slots");
+
+#define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
+#define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+// micro-tiles (8x8 pixels) of the tiles this rank owns; tiles are tile_size^2 pixels,
+// numbered row-major, dealt round-robin over ranks.
+void rank_microtiles(const rt_camera& cam, const rt_params& p, std::vector<int32_t>& out) {
+    const int mtw = (cam.resx + 7) / 8, mth = (cam.resy + 7) / 8;
+    if (p.tile_size <= 0 || p.tile_nranks <= 1) {
+        out.resize((size_t)mtw * mth);
+        for (size_t i = 0; i < out.size(); ++i) out[i] = (int32_t)i;
+        return;
+    }
+    const int ts = ((p.tile_size + 7) / 8) * 8;       // tiles are whole micro-tiles
+    const int tw = (cam.resx + ts - 1) / ts, th = (cam.resy + ts - 1) / ts;
+    const int per = ts / 8;
+    out.clear();
+    for (int t = p.tile_rank; t < tw * th; t += p.tile_nranks) {
+        const int tx = t % tw, ty = t / tw;
+        for (int my = ty * per; my < (ty + 1) * per && my < mth; ++my)
+            for (int mx = tx * per; mx < (tx + 1) * per && mx < mtw; ++mx)
+                out.push_back(my * mtw + mx);
+    }
+}
+
+int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* d_rgb8, int32_t* d_hit_ids,
+                rt_stats* stats, hipStream_t st) {
+    if (p->mode != RT_RENDER_WHITTED) return rt_fail(RT_E_INVALID, "rt_render: mode %d is not built yet", p->mode);
+    const int64_t npix = (int64_t)cam->resx * cam->resy;
+    std::vector<int32_t> tiles;
+    rank_microtiles(*cam, *p, tiles);
+    const int64_t ntiles = (int64_t)tiles.size();
+    const int64_t n0 = ntiles * 64;
+    const int L = s->view.nlights;
+    const bool whole = (p->tile_size <= 0 || p->tile_nranks <= 1);
+
+    void *d_tiles = nullptr, *rays0, *pix0, *accum, *hitany, *ctr;
+    if (!whole) {
+        RTCHK(s->scratch(S_TILES, (size_t)ntiles * 4, &d_tiles));
+        HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)ntiles * 4, hipMemcpyHostToDevice, st), "copy tiles");
+    }
+    RTCHK(s->scratch(S_RAYS0, (size_t)n0 * sizeof(rt_ray), &rays0));
+    RTCHK(s->scratch(S_PIX0, (size_t)n0 * 4, &pix0));
+    RTCHK(s->scratch(S_ACCUM, (size_t)npix * 12, &accum));
+    RTCHK(s->scratch(S_HITANY, (size_t)npix, &hitany));
+    RTCHK(s->scratch(S_COUNTERS, 8 * sizeof(unsigned long long) + 16, &ctr));
+    unsigned long long* d_ctr = (unsigned long long*)ctr;
+    uint32_t* d_total = (uint32_t*)(d_ctr + 8);
+    HIPCHK(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long) + 16, st), "memset counters");
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
+
+    HIPCHK(rtk_generate_tiled(*cam, (const int32_t*)d_tiles, ntiles, 0.f, 0.f, (rt_ray*)rays0, (int32_t*)pix0, st), "k_generate_tiled");
+    HIPCHK(rtk_zero_pixels((const int32_t*)pix0, n0, (float*)accum, st), "k_zero_pixels");
+
+    // pass state
+    const rt_ray* q_rays = (const rt_ray*)rays0;
+    const int32_t* q_pix = (const int32_t*)pix0;
+    const float* q_w = nullptr;          // NULL = weight 1
+    const float* q_nr = nullptr;         // NULL = start_nr ... handled below
+    int64_t n = n0;
+    int64_t passes = 0;
+    std::vector<float> nrfill;
+    for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
+        ++passes;
+        const bool spawn = !p->primary_only && depth < p->max_depth;
+        void *hits, *srays, *sact, *occ, *contrib, *flags = nullptr, *bsums = nullptr;
+        RTCHK(s->scratch(S_HITS, (size_t)n * sizeof(rt_hit), &hits));
+        RTCHK(s->scratch(S_SRAYS, (size_t)n * L * sizeof(rt_ray), &srays));
+        RTCHK(s->scratch(S_SACTIVE, (size_t)n * L * 4, &sact));
+        RTCHK(s->scratch(S_OCC, (size_t)n * L, &occ));
+        RTCHK(s->scratch(S_CONTRIB, (size_t)n * 12, &contrib));
+        if (spawn) {
+            RTCHK(s->scratch(S_FLAGS, (size_t)n * 2, &flags));
+            RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
+        }
+        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, (rt_hit*)hits, st), "k_trace_closest");
+        HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
+                               (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
+                               (uint8_t*)hitany, d_ctr, st), "k_shade_flags");
+        if (L > 0)
+            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, (uint8_t*)occ, st), "k_trace_any");
+        HIPCHK(rtk_shade_lights(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, n, (const uint8_t*)occ,
+                                p->ambient_intensity, cam->center, (float*)contrib, d_ctr, st), "k_shade_lights");
+        HIPCHK(rtk_accumulate(q_pix, (const float*)contrib, n, (float*)accum, st), "k_accumulate");
+        if (!spawn) break;
+        // children -> the other queue
+        const bool toA = (depth % 2) == 0;
+        void *orays, *opix, *ow, *onr;
+        RTCHK(s->scratch(toA ? S_QA_RAYS : S_QB_RAYS, (size_t)n * 2 * sizeof(rt_ray), &orays));
+        RTCHK(s->scratch(toA ? S_QA_PIX : S_QB_PIX, (size_t)n * 2 * 4, &opix));
+        RTCHK(s->scratch(toA ? S_QA_W : S_QB_W, (size_t)n * 2 * 4, &ow));
+        RTCHK(s->scratch(toA ? S_QA_NR : S_QB_NR, (size_t)n * 2 * 4, &onr));
+        const float* nr_in = q_nr;
+        if (!nr_in && p->start_nr != 1.0f) {
+            // first pass with a start index other than 1: materialise it (k_spawn treats NULL as 1.0)
+            void* tmp; RTCHK(s->scratch(toA ? S_QB_NR : S_QA_NR, (size_t)n * 4, &tmp));
+            nrfill.assign((size_t)n, p->start_nr);
+            HIPCHK(hipMemcpyAsync(tmp, nrfill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st), "copy nr");
+            nr_in = (const float*)tmp;
+        }
+        HIPCHK(rtk_compact_children(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, nr_in, (const uint8_t*)flags, 2 * n,
+                                    (uint32_t*)bsums, d_total, (rt_ray*)orays, (int32_t*)opix, (float*)ow, (float*)onr,
+                                    d_ctr, st), "compact children");
+        uint32_t total = 0;
+        HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st), "read child count");
+        HIPCHK(hipStreamSynchronize(st), "sync");
+        q_rays = (const rt_ray*)orays; q_pix = (const int32_t*)opix; q_w = (const float*)ow; q_nr = (const float*)onr;
+        n = (int64_t)total;
+    }
+    HIPCHK(rtk_finalize((const int32_t*)pix0, n0, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8, st), "k_finalize");
+    if (stats) {
+        HIPCHK(hipEventRecord(ev1, st), "event");
+        unsigned long long h[8];
+        HIPCHK(hipMemcpyAsync(h, d_ctr, sizeof h, hipMemcpyDeviceToHost, st), "read counters");
+        HIPCHK(hipStreamSynchronize(st), "sync");
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev0, ev1), "event time");
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        memset(stats, 0, sizeof *stats);
+        stats->rays_reflect = (int64_t)h[3]; stats->rays_refract = (int64_t)h[4];
+        stats->rays_primary = (int64_t)h[0] - stats->rays_reflect - stats->rays_refract;
+        stats->rays_shadow = (int64_t)h[2];
+        stats->passes = passes;
+        stats->kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+int check_args(rt_scene* s, const rt_camera* cam, const rt_params* p, const void* rgb) {
+    if (!s || !cam || !p || !rgb) return rt_fail(RT_E_INVALID, "rt_render: NULL argument");
+    if (cam->resx <= 0 || cam->resy <= 0 || (int64_t)cam->resx * cam->resy > (int64_t)1 << 30)
+        return rt_fail(RT_E_INVALID, "rt_render: bad resolution %dx%d", cam->resx, cam->resy);
+    if (p->max_depth < 0 || p->max_depth > 64) return rt_fail(RT_E_INVALID, "rt_render: max_depth out of range");
+    if (p->tile_nranks > 1 && (p->tile_rank < 0 || p->tile_rank >= p->tile_nranks || p->tile_size <= 0))
+        return rt_fail(RT_E_INVALID, "rt_render: bad tile sharding (rank %d of %d, tile %d)", p->tile_rank, p->tile_nranks, p->tile_size);
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_render_dev(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* d_rgb8, int32_t* d_hit_ids,
+                             rt_stats* stats, void* stream) {
+    RTCHK(check_args(s, cam, p, d_rgb8));
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    return render_impl(s, cam, p, d_rgb8, d_hit_ids, stats, (hipStream_t)stream);
+}
+
+extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* rgb8, int32_t* hit_ids,
+                         rt_stats* stats) {
+    RTCHK(check_args(s, cam, p, rgb8));
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    const size_t npix = (size_t)cam->resx * cam->resy;
+    void *d_rgb, *d_ids = nullptr;
+    RTCHK(s->scratch(0, npix * 3, &d_rgb));
+    if (hit_ids) RTCHK(s->scratch(1, npix * 4, &d_ids));
+    // pixels of other ranks' tiles keep the caller's bytes
+    HIPCHK(hipMemcpy(d_rgb, rgb8, npix * 3, hipMemcpyHostToDevice), "copy rgb in");
+    if (hit_ids) HIPCHK(hipMemcpy(d_ids, hit_ids, npix * 4, hipMemcpyHostToDevice), "copy ids in");
+    RTCHK(render_impl(s, cam, p, (uint8_t*)d_rgb, (int32_t*)d_ids, stats, nullptr));
+    HIPCHK(hipMemcpy(rgb8, d_rgb, npix * 3, hipMemcpyDeviceToHost), "copy rgb out");
+    if (hit_ids) HIPCHK(hipMemcpy(hit_ids, d_ids, npix * 4, hipMemcpyDeviceToHost), "copy ids out");
+    return RT_OK;
+}

@@ -117,3 +117,26 @@ hipError_t rtk_generate_linear(const rt_camera& cam, int64_t first, int64_t n, f
                                hipStream_t st);
 hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float ox, float oy,
                               rt_ray* d_rays, int32_t* d_pix, hipStream_t st);
+
+// kernels_shade.hip
+hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
+                           int spawn_children, int primary_pass, uint8_t* child_flags, rt_ray* srays, int32_t* sactive,
+                           int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, hipStream_t st);
+hipError_t rtk_shade_lights(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
+                            const float* weight, int64_t n, const uint8_t* occluded, float ambient, const float eye[3],
+                            float* contrib, unsigned long long* counters, hipStream_t st);
+hipError_t rtk_accumulate(const int32_t* pix, const float* contrib, int64_t n, float* accum, hipStream_t st);
+int64_t rtk_scan_blocks_needed(int64_t nflags);
+hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
+                                const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
+                                uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
+                                float* onr, unsigned long long* counters, hipStream_t st);
+hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
+                        uint8_t* rgb8, hipStream_t st);
+hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, hipStream_t st);
+
+// kernels_photon.hip
+size_t rtk_knn_lds_bytes(int k);
+hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
+                          int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
+                          float* d_r2, float* d_rgb, const float* d_tables, hipStream_t st);
