@@ -174,7 +174,10 @@ typedef struct rt_stats {
     int64_t rays_primary, rays_shadow, rays_reflect, rays_refract, rays_gather;
     int64_t knn_lookups;
     int64_t passes;             /* wavefront iterations                          */
-    double  kernel_ms;          /* device time of the render (HIP events)        */
+    double  kernel_ms;          /* device time of the whole render (HIP events on the call's stream) */
+    double  trace_closest_ms;   /* sum over passes of the closest-hit kernel's time (HIP events)     */
+    double  trace_any_ms;       /* sum over passes of the any-hit (shadow) kernel's time             */
+    int64_t trace_closest_launches, trace_any_launches;
 } rt_stats;
 
 /* 40-byte photon record, field order of PhotonStruct photon.h:133-141.          */
@@ -221,6 +224,9 @@ typedef struct rt_host_flat rt_host_flat;
 int rt_host_flatten(const rt_scene_desc* desc, rt_host_flat** out, rt_scene_info* info);
 int64_t rt_host_flat_get(const rt_host_flat* f, int which, void* dst, int64_t cap);
 void rt_host_flat_free(rt_host_flat* f);
+/* Host-only: PhotonMap::balance (photon.cpp:133-254) exactly as rt_photonmap_build
+ * runs it before uploading; photons[1..n] are permuted into heap order in place. */
+int rt_host_photon_balance(rt_photon* photons, int64_t n);
 
 /* ---- traversal ----------------------------------------------------------- */
 

@@ -341,6 +341,7 @@ static int32_t closest(orc_scene* s, v3 ori, v3 dir, float* nearest_out, v3* hit
     float nearestDis = 1e9f; int32_t nearest = -1; v3 hitPoint = V(0, 0, 0);
     int culling = (s->flags & RT_SCENE_CULLING) != 0;
     s->check_time++;
+    s->c.rays_traced++;
     for (int j = 0; j < s->nobj; j++) {
         kdnode* root = s->roots[j];
         if (!node_hit(s, root, o, d)) continue;
@@ -348,6 +349,7 @@ static int32_t closest(orc_scene* s, v3 ori, v3 dir, float* nearest_out, v3* hit
         stack[sp++] = root;
         while (sp > 0) {
             kdnode* node = stack[--sp];
+            s->c.node_pops++;
             if (!node_hit(s, node, o, d)) continue;
             if (!node->is_leaf) {
                 if (node->left && node_hit(s, node->left, o, d)) stack[sp++] = node->left;
@@ -389,6 +391,7 @@ static int any_hit(orc_scene* s, v3 point, v3 rayDir, int use_tmax, float tLight
     float o[3], d[3]; vstore(o, point); vstore(d, rayDir);
     float nearestDis = 1e9f;
     s->check_time++;
+    s->c.rays_traced++;
     for (int j = 0; j < s->nobj; j++) {
         kdnode* root = s->roots[j];
         if (!node_hit(s, root, o, d)) continue;
@@ -396,6 +399,7 @@ static int any_hit(orc_scene* s, v3 point, v3 rayDir, int use_tmax, float tLight
         stack[sp++] = root;
         while (sp > 0) {
             kdnode* node = stack[--sp];
+            s->c.node_pops++;
             if (!node_hit(s, node, o, d)) continue;
             if (!node->is_leaf) {
                 if (node->left && node_hit(s, node->left, o, d)) stack[sp++] = node->left;
@@ -436,6 +440,16 @@ void orc_trace_closest(orc_scene* s, const rt_ray* rays, int64_t n, rt_hit* out)
 void orc_trace_any(orc_scene* s, const rt_ray* rays, const float* tmax, int64_t n, uint8_t* occ) {
     for (int64_t i = 0; i < n; i++)
         occ[i] = (uint8_t)any_hit(s, vload(rays[i].o), vload(rays[i].d), tmax != NULL, tmax ? tmax[i] : 0.0f);
+}
+
+/* the ray IsInShadow traces, hw4.cpp:961-963: origin = point + normal*shadowBias,
+ * dir = normalize(light - origin); tlight = (light - origin).length() (hw4.cpp:967) */
+void orc_shadow_ray(const float point[3], const float light[3], const float normal[3], float bias,
+                    rt_ray* ray, float* tlight) {
+    v3 p = vadd(vload(point), vmuls(vload(normal), bias));
+    v3 d = vnorm(vsub(vload(light), p));
+    vstore(ray->o, p); vstore(ray->d, d);
+    if (tlight) *tlight = vlen(vsub(vload(light), p));
 }
 
 /* ---- camera: hw4.cpp:242-276, 559 ---------------------------------------- */

@@ -33,6 +33,8 @@ typedef struct orc_counters {
     int64_t leaf_refs_read; /* leaf list entries walked                     */
     int64_t knn_lookups, knn_node_visits, knn_found;
     double  average_check;  /* `averageCheck`, hw4.cpp:1106                  */
+    int64_t node_pops;      /* nodes popped (each is box-tested a second time, hw4.cpp:825) */
+    int64_t rays_traced;    /* closest + any traversals                      */
 } orc_counters;
 
 /* flattened view of the KD trees, for comparing builders */
@@ -67,6 +69,9 @@ int orc_sphere_test(const float center[3], float radius, const float ori[3], con
 
 void orc_trace_closest(orc_scene* s, const rt_ray* rays, int64_t n, rt_hit* out);
 void orc_trace_any(orc_scene* s, const rt_ray* rays, const float* tmax, int64_t n, uint8_t* occ);
+
+void orc_shadow_ray(const float point[3], const float light[3], const float normal[3], float bias,
+                    rt_ray* ray, float* tlight);
 
 /* Camera::CalcPlaneParameters, hw4.cpp:242-266 (view is normalised first as
  * the parser does, hw4.cpp:559) */

@@ -57,7 +57,9 @@ class rt_params(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("rays_primary", _i64), ("rays_shadow", _i64), ("rays_reflect", _i64), ("rays_refract", _i64),
-                ("rays_gather", _i64), ("knn_lookups", _i64), ("passes", _i64), ("kernel_ms", C.c_double)]
+                ("rays_gather", _i64), ("knn_lookups", _i64), ("passes", _i64), ("kernel_ms", C.c_double),
+                ("trace_closest_ms", C.c_double), ("trace_any_ms", C.c_double),
+                ("trace_closest_launches", _i64), ("trace_any_launches", _i64)]
 
 
 # numpy views of the POD records
@@ -71,7 +73,7 @@ assert ray_dtype.itemsize == 24 and hit_dtype.itemsize == 20 and photon_dtype.it
 SYMBOLS = [
     "rt_init", "rt_last_error", "rt_abi_version",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get",
-    "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free",
+    "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_irradiance", "rt_photon_irradiance_dev",
@@ -106,6 +108,7 @@ def load():
     L.rt_host_flat_get.restype = i64
     L.rt_host_flat_free.argtypes = [vp]
     L.rt_host_flat_free.restype = None
+    L.rt_host_photon_balance.argtypes = [vp, i64]
     L.rt_trace_closest.argtypes = [vp, vp, i64, vp]
     L.rt_trace_closest_dev.argtypes = [vp, vp, i64, vp, vp]
     L.rt_trace_any.argtypes = [vp, vp, vp, i64, vp]

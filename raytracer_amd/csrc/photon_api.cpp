@@ -79,6 +79,12 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n) {
     return upload_heap(s, which, photons, n);
 }
 
+int rt_host_photon_balance(rt_photon* photons, int64_t n) {
+    if (!photons || n < 0) return rt_fail(RT_E_INVALID, "rt_host_photon_balance: bad argument");
+    try { rt_photon_balance_host(photons, n); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
+    return RT_OK;
+}
+
 int rt_photon_knn_dev(rt_scene* s, int which, const float* d_pos3, int64_t q, int k, float maxDist, int32_t* d_idx,
                       float* d_dist2, int32_t* d_found, float* d_radius2, void* stream) {
     RTCHK(check_map(s, which, k, "rt_photon_knn_dev"));

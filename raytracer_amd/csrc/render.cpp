@@ -65,6 +65,12 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     HIPCHK(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long) + 16, st), "memset counters");
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;      // per-kernel event pairs: [closest begin, closest end, any begin, any end] per pass
+    auto mark = [&](void) -> int {
+        if (!stats) return RT_OK;
+        hipEvent_t e; HIPCHK(hipEventCreate(&e), "event"); HIPCHK(hipEventRecord(e, st), "event"); kev.push_back(e);
+        return RT_OK;
+    };
     if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
 
     HIPCHK(rtk_generate_tiled(*cam, (const int32_t*)d_tiles, ntiles, 0.f, 0.f, (rt_ray*)rays0, (int32_t*)pix0, st), "k_generate_tiled");
@@ -91,12 +97,16 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             RTCHK(s->scratch(S_FLAGS, (size_t)n * 2, &flags));
             RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
         }
+        RTCHK(mark());
         HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, (rt_hit*)hits, st), "k_trace_closest");
+        RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
                                (uint8_t*)hitany, d_ctr, st), "k_shade_flags");
+        RTCHK(mark());
         if (L > 0)
             HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, (uint8_t*)occ, st), "k_trace_any");
+        RTCHK(mark());
         HIPCHK(rtk_shade_lights(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, n, (const uint8_t*)occ,
                                 p->ambient_intensity, cam->center, (float*)contrib, d_ctr, st), "k_shade_lights");
         HIPCHK(rtk_accumulate(q_pix, (const float*)contrib, n, (float*)accum, st), "k_accumulate");
@@ -140,6 +150,14 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         stats->rays_shadow = (int64_t)h[2];
         stats->passes = passes;
         stats->kernel_ms = ms;
+        for (size_t i = 0; i + 3 < kev.size(); i += 4) {
+            float a = 0.f, b = 0.f;
+            HIPCHK(hipEventElapsedTime(&a, kev[i], kev[i + 1]), "event time");
+            HIPCHK(hipEventElapsedTime(&b, kev[i + 2], kev[i + 3]), "event time");
+            stats->trace_closest_ms += a; stats->trace_any_ms += b;
+            stats->trace_closest_launches += 1; stats->trace_any_launches += (L > 0) ? 1 : 0;
+        }
+        for (hipEvent_t e : kev) (void)hipEventDestroy(e);
     }
     return RT_OK;
 }

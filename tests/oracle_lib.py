@@ -20,7 +20,8 @@ vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 class orc_counters(C.Structure):
     _fields_ = [("rays_primary", i64), ("rays_shadow", i64), ("rays_reflect", i64), ("rays_refract", i64),
                 ("box_tests", i64), ("tri_tests", i64), ("leaf_refs_read", i64), ("knn_lookups", i64),
-                ("knn_node_visits", i64), ("knn_found", i64), ("average_check", C.c_double)]
+                ("knn_node_visits", i64), ("knn_found", i64), ("average_check", C.c_double),
+                ("node_pops", i64), ("rays_traced", i64)]
 
 
 class orc_kd_flat(C.Structure):
@@ -52,6 +53,7 @@ def oracle():
         L.orc_sphere_test.argtypes = [vp, f32, vp, vp, vp]
         L.orc_trace_closest.argtypes = [vp, vp, i64, vp]
         L.orc_trace_any.argtypes = [vp, vp, vp, i64, vp]
+        L.orc_shadow_ray.argtypes = [vp, vp, vp, f32, vp, vp]
         L.orc_camera_setup.argtypes = [vp, vp, f32, i32, i32, C.POINTER(abi.rt_camera)]
         L.orc_primary_ray.argtypes = [C.POINTER(abi.rt_camera), f32, f32, vp]
         L.orc_render_whitted.argtypes = [vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), vp, vp, vp]
@@ -155,6 +157,18 @@ class OracleScene:
         self.L.orc_render_whitted(self.h, C.byref(cam), C.byref(params), rgb.ctypes.data, ids.ctypes.data,
                                   None if rad is None else rad.ctypes.data)
         return rgb.reshape(cam.resy, cam.resx, 3), ids, rad
+
+
+def oracle_shadow_rays(points, light, normals, bias=1e-4):
+    points = np.ascontiguousarray(points, np.float32); normals = np.ascontiguousarray(normals, np.float32)
+    light = np.ascontiguousarray(light, np.float32)
+    rays = np.zeros((points.shape[0], 6), np.float32); tl = np.zeros(points.shape[0], np.float32)
+    L = oracle()
+    for i in range(points.shape[0]):
+        t = C.c_float()
+        L.orc_shadow_ray(points[i].ctypes.data, light.ctypes.data, normals[i].ctypes.data, bias, rays[i].ctypes.data, C.byref(t))
+        tl[i] = t.value
+    return rays, tl
 
 
 def oracle_camera(eye, view_raw, fov, resx, resy):

@@ -1,0 +1,43 @@
+"""CPU tests of the multi-rank path (gloo, world_size 2 and 4): tile dealing, per-rank compaction,
+gather to rank 0 and re-assembly, exactly the code bench.py runs over RCCL on the 8-GPU node
+(--dry-run replaces the GPU render with a rank-coloured fill)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+@pytest.mark.parametrize("res,nranks", [((3840, 2160), 8), ((200, 136), 3), ((64, 64), 2), ((65, 1), 4)])
+def test_tiles_partition_the_frame(res, nranks):
+    parts = [bench.rank_pixel_index(res[0], res[1], r, nranks) for r in range(nranks)]
+    allp = np.concatenate(parts)
+    assert allp.size == res[0] * res[1] and np.array_equal(np.sort(allp), np.arange(res[0] * res[1]))
+    if res == (3840, 2160):
+        sizes = [p.size for p in parts]
+        assert max(sizes) - min(sizes) <= 64 * 64 * 2           # round-robin dealing balances the load
+
+
+def test_weak_scaling_frames():
+    for n in (1, 2, 4, 8):
+        w, h = bench.frame_for(n)
+        assert w * h == n * 3840 * 2160
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_to_rank0_over_gloo(world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29530 + world), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["assembled_ok"] and j["n_gpus"] == world and sum(j["pixels_per_rank"]) == j["frame"][0] * j["frame"][1]

@@ -1,0 +1,143 @@
+"""GPU parity: photon-map kNN / irradiance (HIP, LDS max-heaps) against the reference's
+fixture (LocatePhoton / CalcIrradiance called through oracle/_ref) and the CPU oracle.
+Bar: bit-exact index lists (in the reference's np.index order), squared distances, radius
+and irradiance."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from raytracer_amd import abi, host, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(name):
+    with np.load(os.path.join(ol.GOLDEN, name)) as z:
+        return {k: np.ascontiguousarray(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def gscene():
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    s = host.Scene(sd)
+    yield s
+    s.close()
+
+
+def _oracle_knn(heap, qp, k, maxd):
+    L = ol.oracle()
+    q = qp.shape[0]; n = heap.size - 1
+    idx = np.zeros((q, k), np.int32); d2 = np.zeros((q, k), np.float32)
+    found = np.zeros(q, np.int32); r2 = np.zeros(q, np.float32); vis = C.c_int64(0)
+    L.orc_pmap_knn(heap.ctypes.data, n, qp.ctypes.data, q, k, maxd, idx.ctypes.data, d2.ctypes.data, found.ctypes.data,
+                   r2.ctypes.data, C.byref(vis))
+    return idx, d2, found, r2
+
+
+def _oracle_irr(heap, qp, qn, k, maxd):
+    rgb = np.zeros((qp.shape[0], 3), np.float32)
+    ol.oracle().orc_pmap_irradiance(heap.ctypes.data, heap.size - 1, qp.ctypes.data, qn.ctypes.data, qp.shape[0], k, maxd,
+                                    rgb.ctypes.data)
+    return rgb
+
+
+@pytest.mark.parametrize("tag", ["r1", "r01", "r002"])
+def test_knn_and_irradiance_vs_reference_fixture(gscene, tag):
+    g = _load("photon_golden.npz")
+    heap = g["heap"].view(abi.photon_dtype).copy()
+    gscene.photonmap_upload(abi.RT_PMAP_GLOBAL, heap)
+    k, maxd = g["k"].item(), g[f"maxd_{tag}"].item()
+    idx, d2, found, r2 = gscene.photon_knn(abi.RT_PMAP_GLOBAL, g["qpos"], k, maxd)
+    assert np.array_equal(found, g[f"found_{tag}"]) and np.array_equal(idx, g[f"idx_{tag}"])
+    assert d2.tobytes() == g[f"d2_{tag}"].tobytes() and r2.tobytes() == g[f"r2_{tag}"].tobytes()
+    rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, g["qpos"], g["qnrm"], k, maxd)
+    assert rgb.tobytes() == g[f"rgb_{tag}"].tobytes()
+
+
+def test_build_from_unbalanced_equals_reference_heap(gscene):
+    g = _load("photon_golden.npz")
+    stored = g["stored"].view(abi.photon_dtype).copy()
+    heap = g["heap"].view(abi.photon_dtype)
+    out = gscene.photonmap_build(abi.RT_PMAP_CAUSTIC, stored)
+    for f in ("position", "phi", "theta", "plane"):
+        assert np.array_equal(out[f][1:], heap[f][1:]), f
+    idx, d2, found, r2 = gscene.photon_knn(abi.RT_PMAP_CAUSTIC, g["qpos"], g["k"].item(), 0.1)
+    assert np.array_equal(idx, g["idx_r01"]) and np.array_equal(found, g["found_r01"])
+
+
+def _random_map(n, seed):
+    rng = np.random.default_rng(seed)
+    a = np.zeros(n + 1, abi.photon_dtype)
+    a["position"][1:] = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    a["position"][1: 1 + n // 3, 1] = -0.5
+    a["power"][1:] = rng.uniform(0, 1e-4, (n, 3)).astype(np.float32)
+    a["phi"][1:] = rng.integers(0, 256, n); a["theta"][1:] = rng.integers(0, 256, n)
+    return a
+
+
+def test_large_map_many_k_vs_oracle(gscene):
+    n = 300_000
+    a = _random_map(n, 21)
+    heap = gscene.photonmap_build(abi.RT_PMAP_GLOBAL, a)           # balanced in place by the product
+    chk = a.copy()
+    rng = np.random.default_rng(22)
+    for k, maxd, q in ((1, 1.0, 700), (8, 0.05, 1000), (50, 0.2, 1025), (100, 1.0, 2000), (100, 0.01, 500), (287, 0.3, 200)):
+        qp = rng.uniform(-0.55, 0.55, (q, 3)).astype(np.float32)
+        qp[: q // 4, 1] = -0.5
+        qn = rng.normal(size=(q, 3)).astype(np.float32)
+        gi, gd, gf, gr = gscene.photon_knn(abi.RT_PMAP_GLOBAL, qp, k, maxd)
+        oi, od, of, orr = _oracle_knn(heap, qp, k, maxd)
+        assert np.array_equal(gf, of) and np.array_equal(gi, oi), (k, maxd)
+        assert gd.tobytes() == od.tobytes() and gr.tobytes() == orr.tobytes()
+        rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, k, maxd)
+        assert rgb.tobytes() == _oracle_irr(heap, qp, qn, k, maxd).tobytes(), (k, maxd)
+
+
+def test_tiny_and_empty_maps(gscene):
+    rng = np.random.default_rng(5)
+    qp = rng.uniform(-0.5, 0.5, (130, 3)).astype(np.float32)
+    for n in (0, 1, 2, 3, 4, 5, 9, 17):
+        a = _random_map(n, 30 + n)
+        heap = gscene.photonmap_build(abi.RT_PMAP_GLOBAL, a)
+        gi, gd, gf, gr = gscene.photon_knn(abi.RT_PMAP_GLOBAL, qp, 4, 2.0)
+        oi, od, of, orr = _oracle_knn(heap, qp, 4, 2.0)
+        assert np.array_equal(gf, of) and np.array_equal(gi, oi), n
+        assert gd.tobytes() == od.tobytes() and gr.tobytes() == orr.tobytes()
+    # ragged / empty query sets
+    for q in (0, 1, 63, 65):
+        gi, gd, gf, gr = gscene.photon_knn(abi.RT_PMAP_GLOBAL, qp[:q], 4, 2.0)
+        assert gf.shape == (q,)
+
+
+def test_error_paths(gscene):
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    fresh = host.Scene(sd)
+    qp = np.zeros((4, 3), np.float32)
+    with pytest.raises(abi.RtError) as e:
+        fresh.photon_knn(abi.RT_PMAP_GLOBAL, qp, 10, 1.0)              # no map uploaded
+    assert e.value.code == -5
+    with pytest.raises(abi.RtError) as e:
+        gscene.photon_knn(abi.RT_PMAP_GLOBAL, qp, 100000, 1.0)         # k beyond the LDS heap limit
+    assert e.value.code == -4
+    fresh.close()
+
+
+def test_dev_entry_points(gscene):
+    import torch
+    g = _load("photon_golden.npz")
+    heap = g["heap"].view(abi.photon_dtype).copy()
+    gscene.photonmap_upload(abi.RT_PMAP_GLOBAL, heap)
+    q, k = g["qpos"].shape[0], g["k"].item()
+    dp = torch.from_numpy(g["qpos"]).cuda(); dn = torch.from_numpy(g["qnrm"]).cuda()
+    di = torch.zeros((q, k), dtype=torch.int32, device="cuda"); dd = torch.zeros((q, k), dtype=torch.float32, device="cuda")
+    df = torch.zeros(q, dtype=torch.int32, device="cuda"); dr = torch.zeros(q, dtype=torch.float32, device="cuda")
+    dc = torch.zeros((q, 3), dtype=torch.float32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    abi.check(gscene.L.rt_photon_knn_dev(gscene.h, 0, dp.data_ptr(), q, k, 1.0, di.data_ptr(), dd.data_ptr(), df.data_ptr(),
+                                         dr.data_ptr(), st))
+    abi.check(gscene.L.rt_photon_irradiance_dev(gscene.h, 0, dp.data_ptr(), dn.data_ptr(), q, k, 1.0, dc.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(di.cpu().numpy(), g["idx_r1"]) and dc.cpu().numpy().tobytes() == g["rgb_r1"].tobytes()

@@ -1,0 +1,163 @@
+"""GPU parity: rt_render (wavefront Whitted renderer, HIP) against the reference's fixtures
+and the CPU oracle.  Bars: primary hit ids bit-exact; 8-bit radiance within 1 LSB on at most
+0.2 % of the pixels (pow() on the device is not glibc's, and the wavefront sums the same
+terms in a different association than the recursion: north_star allows a stated tolerance)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from raytracer_amd import abi, host, scene
+
+pytestmark = pytest.mark.gpu
+RGB_MAX_LSB = 1
+RGB_MAX_FRACTION = 0.002
+
+
+def _load(name):
+    with np.load(os.path.join(ol.GOLDEN, name)) as z:
+        return {k: np.ascontiguousarray(z[k]) for k in z.files}
+
+
+def _assert_rgb_close(got, want):
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32)).max(-1)
+    assert d.max() <= RGB_MAX_LSB, f"max byte difference {d.max()}"
+    frac = (d > 0).mean()
+    assert frac <= RGB_MAX_FRACTION, f"{(d > 0).sum()} pixels differ ({frac:.5f})"
+    return int((d > 0).sum())
+
+
+@pytest.fixture(scope="module")
+def gscene(monkey_sd):
+    s = host.Scene(monkey_sd)
+    yield s
+    s.close()
+
+
+def test_monkey256_frame_vs_reference_binary(gscene, monkey_sd):
+    ref = _load("monkey256_ref.npz"); hits = _load("monkey256_hits.npz")
+    cam = host.camera_for(monkey_sd)
+    rgb, ids, st = gscene.render(cam, host.default_params("hw4"), want_ids=True)
+    assert np.array_equal(ids.reshape(256, 256).T.ravel(), hits["prim"])          # bit-exact hit ids
+    ndiff = _assert_rgb_close(rgb, ref["rgb"])
+    print("pixels differing by 1 LSB from the reference binary:", ndiff)
+    # ray census of the reference run
+    assert (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow) == (65536, 9827, 0, 28805)
+    assert st.passes >= 2
+
+
+def test_4k_primary_hit_ids_digest(gscene, monkey_sd):
+    """BASELINE config 2: 3840x2160, primary + shadow rays only, hit ids bit-exact vs the reference."""
+    g = _load("monkey4k_hits_digest.npz")
+    cam = host.camera_for(monkey_sd, (3840, 2160))
+    rgb, ids, st = gscene.render(cam, host.default_params("hw4", primary_only=1), want_ids=True)
+    ids_xy = np.ascontiguousarray(ids.reshape(2160, 3840).T)
+    assert int((ids_xy >= 0).sum()) == g["hit_pixels"].item()
+    assert np.array_equal(ids_xy[::8, ::8], g["sub_ids"])
+    assert hashlib.sha256(ids_xy.tobytes()).hexdigest() == g["sha256_ids_xy"].item()
+    assert st.rays_primary == 3840 * 2160 and st.rays_shadow == g["hit_pixels"].item() and st.rays_reflect == 0
+    assert st.passes == 1
+
+
+def test_odd_resolution_vs_oracle(gscene, monkey_sd):
+    o = ol.OracleScene(monkey_sd)
+    for res in ((61, 37), (8, 8), (1, 1), (130, 9)):
+        cam = host.camera_for(monkey_sd, res)
+        rgb, ids, st = gscene.render(cam, host.default_params("hw4"), want_ids=True)
+        o.reset()
+        orgb, oids, _ = o.render_whitted(ol.oracle_camera(monkey_sd.eye, monkey_sd.view, monkey_sd.fov, *res),
+                                         host.default_params("hw4"))
+        assert np.array_equal(ids, oids), res
+        d = np.abs(rgb.astype(int) - orgb.astype(int))
+        assert d.max() <= 1, res
+    o.close()
+
+
+def test_tile_sharding_is_byte_identical(gscene, monkey_sd):
+    """N-rank image == 1-rank image, byte for byte."""
+    cam = host.camera_for(monkey_sd, (200, 136))
+    whole, wids, _ = gscene.render(cam, host.default_params("hw4"), want_ids=True)
+    for nranks, ts in ((2, 64), (3, 32), (8, 16)):
+        rgb = np.full(200 * 136 * 3, 7, np.uint8); ids = np.full(200 * 136, -5, np.int32)
+        L = gscene.L
+        import ctypes as C
+        total = abi.rt_stats()
+        rays = 0
+        for r in range(nranks):
+            p = host.default_params("hw4", tile_size=ts, tile_rank=r, tile_nranks=nranks)
+            st = abi.rt_stats()
+            abi.check(L.rt_render(gscene.h, C.byref(cam), C.byref(p), rgb.ctypes.data, ids.ctypes.data, C.byref(st)))
+            rays += st.rays_primary
+        assert rays == 200 * 136
+        assert np.array_equal(rgb.reshape(136, 200, 3), whole) and np.array_equal(ids, wids)
+
+
+def _glass_scene():
+    """floor + wall + a refracting quad and a mirror quad: exercises hw4.cpp:897-924 (both children)."""
+    t = ["E 0 0 -1", "V 0 0 1", "F 45", "R 96 96", "L 2 3 -2", "ML -2 2 -1 1 1 1 0.6",
+         "M 0.9 0.8 0.3 0.1 0.8 0.4 12 0.0 0.0 1.0",
+         "T -2 -0.5 -1 -2 -0.5 3 2 -0.5 3 0 1 0", "T -2 -0.5 -1 2 -0.5 3 2 -0.5 -1 0 1 0",
+         "T -2 -0.5 3 -2 2 3 2 2 3 0 0 -1", "T -2 -0.5 3 2 2 3 2 -0.5 3 0 0 -1", "O",
+         "M 0.2 0.3 0.9 0.1 0.3 0.6 30 0.2 0.7 1.5",
+         "T -0.6 -0.4 1.0 0.1 -0.4 1.2 0.1 0.5 1.2 0.3 0 -1", "T -0.6 -0.4 1.0 0.1 0.5 1.2 -0.6 0.5 1.0 0.3 0 -1", "O",
+         "M 0.9 0.9 0.9 0.05 0.2 0.8 60 0.85 0.0 1.0",
+         "T 0.2 -0.4 1.4 0.9 -0.4 0.9 0.9 0.6 0.9 -0.5 0 -0.8", "T 0.2 -0.4 1.4 0.9 0.6 0.9 0.2 0.6 1.4 -0.5 0 -0.8", "O"]
+    return scene.parse_scene_text("\n".join(t) + "\n")
+
+
+def test_reflection_and_refraction_vs_oracle():
+    sd = _glass_scene()
+    g = host.Scene(sd); o = ol.OracleScene(sd)
+    cam = host.camera_for(sd)
+    rgb, ids, st = g.render(cam, host.default_params("hw4"), want_ids=True)
+    orgb, oids, orad = o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, 96, 96), host.default_params("hw4"),
+                                        want_radiance=True)
+    c = o.counters()
+    assert np.array_equal(ids, oids)
+    assert (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow) == \
+           (c.rays_primary, c.rays_reflect, c.rays_refract, c.rays_shadow)
+    assert st.rays_refract > 0 and st.rays_reflect > 0 and st.passes > 3
+    _assert_rgb_close(rgb, orgb)
+    g.close(); o.close()
+
+
+def test_render_dev_matches_host_entry(gscene, monkey_sd):
+    import ctypes as C
+    import torch
+    cam = host.camera_for(monkey_sd, (128, 128))
+    p = host.default_params("hw4")
+    rgb, ids, _ = gscene.render(cam, p, want_ids=True)
+    d_rgb = torch.zeros(128 * 128 * 3, dtype=torch.uint8, device="cuda")
+    d_ids = torch.zeros(128 * 128, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        abi.check(gscene.L.rt_render_dev(gscene.h, C.byref(cam), C.byref(p), d_rgb.data_ptr(), d_ids.data_ptr(), None,
+                                         C.c_void_p(s.cuda_stream)))
+    s.synchronize()
+    assert np.array_equal(d_rgb.cpu().numpy().reshape(128, 128, 3), rgb) and np.array_equal(d_ids.cpu().numpy(), ids)
+
+
+def test_generate_primary_dev_matches_reference_rays(gscene, monkey_sd):
+    import ctypes as C
+    import torch
+    g = _load("monkey256_hits.npz")
+    cam = host.camera_for(monkey_sd)
+    d = torch.zeros(65536 * 6, dtype=torch.float32, device="cuda")
+    abi.check(gscene.L.rt_generate_primary_dev(gscene.h, C.byref(cam), 0, 65536, 0.0, 0.0, d.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert d.cpu().numpy().tobytes() == g["rays"].tobytes()             # index = x*resy + y, as the fixture
+
+
+def test_bad_arguments_are_errors_not_crashes(gscene, monkey_sd):
+    import ctypes as C
+    cam = host.camera_for(monkey_sd, (16, 16))
+    p = host.default_params("hw4", mode=7)
+    buf = np.zeros(16 * 16 * 3, np.uint8)
+    assert gscene.L.rt_render(gscene.h, C.byref(cam), C.byref(p), buf.ctypes.data, None, None) < 0
+    assert gscene.L.rt_render(gscene.h, C.byref(cam), None, buf.ctypes.data, None, None) < 0
+    p = host.default_params("hw4", tile_size=16, tile_rank=3, tile_nranks=2)
+    assert gscene.L.rt_render(gscene.h, C.byref(cam), C.byref(p), buf.ctypes.data, None, None) < 0
+    assert gscene.L.rt_trace_closest(gscene.h, None, 5, None) < 0
+    assert b"rt_trace_closest" in gscene.L.rt_last_error()
