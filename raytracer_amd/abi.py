@@ -6,6 +6,7 @@ of the library itself fails with RT_E_NODEVICE when no gfx950 GPU is usable.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -92,6 +93,14 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm wheels bundle their own HIP runtime under the same soname; whichever copy is
+    # mapped first serves the whole process, and torch cannot initialise on top of the system
+    # copy.  Host programs that also use torch must therefore import it first -- do it for them.
+    if "torch" not in sys.modules and not os.environ.get("RT_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     p = lib_path()
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: build it with `make -C raytracer_amd/csrc` "

@@ -58,10 +58,36 @@ __device__ __forceinline__ bool load_hit(const DevSceneView& sc, const rt_ray* _
 
 }  // namespace
 
-// counters[0]=valid rays in, [1]=hits, [2]=shadow rays, [3]=reflect children, [4]=refract children
-__device__ __forceinline__ void wave_count(unsigned long long* ctr, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
+// counters[0]=valid rays in, [1]=hits, [3]=reflect children, [4]=refract children.
+// No global atomics: all waves of a frame adding to one address serialise (2 atomics per wave
+// cost 1.5 ms on a 4K frame).  Each block writes its pair of sums; k_reduce_pairs adds them up.
+__device__ __forceinline__ void block_count2(unsigned long long* ctr /* per-block pairs */, bool p0, bool p1) {
+    __shared__ unsigned int part[2];
+    if (threadIdx.x < 2) part[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+    if ((threadIdx.x & 63) == 0) {
+        if (m0) atomicAdd(&part[0], (unsigned)__builtin_popcountll(m0));
+        if (m1) atomicAdd(&part[1], (unsigned)__builtin_popcountll(m1));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) reinterpret_cast<unsigned int*>(ctr)[2 * blockIdx.x + threadIdx.x] = part[threadIdx.x];
+}
+
+// sums the per-block pairs written by block_count2 into counters[0], counters[1]
+extern "C" __global__ void __launch_bounds__(1024)
+k_reduce_pairs(const unsigned int* __restrict__ pairs, int64_t nblocks, unsigned long long* __restrict__ counters) {
+    __shared__ unsigned long long red[2][16];
+    unsigned long long a = 0, b = 0;
+    for (int64_t i = threadIdx.x; i < nblocks; i += 1024) { a += pairs[2 * i]; b += pairs[2 * i + 1]; }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
+        counters[threadIdx.x] += t;
+    }
 }
 
 // Per traced ray: child flags (2 per ray), one biased shadow ray per light, and for the
@@ -70,14 +96,13 @@ extern "C" __global__ void __launch_bounds__(256)
 k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restrict__ hits,
               const int32_t* __restrict__ pix, int64_t n, int spawn_children, int primary_pass,
               uint8_t* __restrict__ child_flags, rt_ray* __restrict__ srays, int32_t* __restrict__ sactive,
-              int32_t* __restrict__ hit_ids, uint8_t* __restrict__ hit_any, unsigned long long* __restrict__ counters) {
+              int32_t* __restrict__ hit_ids, uint8_t* __restrict__ hit_any, unsigned long long* __restrict__ block_pairs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool inb = i < n;
     const int px = inb ? pix[i] : -1;
     HitCtx c;
     const bool hit = (px >= 0) && load_hit(sc, rays, hits, i, c);
-    wave_count(counters + 0, px >= 0);
-    wave_count(counters + 1, hit);
+    block_count2(block_pairs, px >= 0, hit);
     if (!inb) return;
     const int L = sc.nlights;
     if (primary_pass && px >= 0) {
@@ -119,11 +144,6 @@ k_shade_lights(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* _
     float cr = 0.f, cg = 0.f, cb = 0.f;
     HitCtx c;
     const bool hit = inb && pix[i] >= 0 && load_hit(sc, rays, hits, i, c);
-    {
-        const unsigned long long hm = __ballot(hit);
-        if (hm && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(hm))
-            atomicAdd(counters + 2, (unsigned long long)__builtin_popcountll(hm) * (unsigned long long)sc.nlights);
-    }
     if (!inb) return;
     if (hit) {
         const DevMaterial m = sc.materials[c.mat];
@@ -313,10 +333,14 @@ static inline unsigned gridf(int64_t n, int b) { return (unsigned)((n + b - 1) /
 
 hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
                            int spawn_children, int primary_pass, uint8_t* child_flags, rt_ray* srays, int32_t* sactive,
-                           int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, hipStream_t st) {
+                           int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, unsigned int* block_pairs,
+                           hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_shade_flags, dim3(gridf(n, 256)), dim3(256), 0, st, sc, rays, hits, pix, n, spawn_children,
-                       primary_pass, child_flags, srays, sactive, hit_ids, hit_any, counters);
+    const unsigned nb = gridf(n, 256);
+    hipLaunchKernelGGL(k_shade_flags, dim3(nb), dim3(256), 0, st, sc, rays, hits, pix, n, spawn_children,
+                       primary_pass, child_flags, srays, sactive, hit_ids, hit_any,
+                       reinterpret_cast<unsigned long long*>(block_pairs));
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, block_pairs, (int64_t)nb, counters);
     return hipGetLastError();
 }
 

@@ -11,9 +11,9 @@ namespace {
 
 enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
-    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS
+    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS
 };
-static_assert(S_COUNTERS < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_PAIRS < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -87,7 +87,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
         ++passes;
         const bool spawn = !p->primary_only && depth < p->max_depth;
-        void *hits, *srays, *sact, *occ, *contrib, *flags = nullptr, *bsums = nullptr;
+        void *hits, *srays, *sact, *occ, *contrib, *flags = nullptr, *bsums = nullptr, *pairs;
+        RTCHK(s->scratch(S_PAIRS, (size_t)((n + 255) / 256) * 8 + 16, &pairs));
         RTCHK(s->scratch(S_HITS, (size_t)n * sizeof(rt_hit), &hits));
         RTCHK(s->scratch(S_SRAYS, (size_t)n * L * sizeof(rt_ray), &srays));
         RTCHK(s->scratch(S_SACTIVE, (size_t)n * L * 4, &sact));
@@ -102,7 +103,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
-                               (uint8_t*)hitany, d_ctr, st), "k_shade_flags");
+                               (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, st), "k_shade_flags");
         RTCHK(mark());
         if (L > 0)
             HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, (uint8_t*)occ, st), "k_trace_any");
@@ -147,7 +148,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         memset(stats, 0, sizeof *stats);
         stats->rays_reflect = (int64_t)h[3]; stats->rays_refract = (int64_t)h[4];
         stats->rays_primary = (int64_t)h[0] - stats->rays_reflect - stats->rays_refract;
-        stats->rays_shadow = (int64_t)h[2];
+        stats->rays_shadow = (int64_t)h[1] * L;      // one shadow ray per hit and light (hw4.cpp:929-931)
         stats->passes = passes;
         stats->kernel_ms = ms;
         for (size_t i = 0; i + 3 < kev.size(); i += 4) {

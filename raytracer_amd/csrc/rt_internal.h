@@ -121,7 +121,8 @@ hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int6
 // kernels_shade.hip
 hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
                            int spawn_children, int primary_pass, uint8_t* child_flags, rt_ray* srays, int32_t* sactive,
-                           int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, hipStream_t st);
+                           int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, unsigned int* block_pairs,
+                           hipStream_t st);   // block_pairs: scratch, 2 x ceil(n/256) uint32
 hipError_t rtk_shade_lights(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
                             const float* weight, int64_t n, const uint8_t* occluded, float ambient, const float eye[3],
                             float* contrib, unsigned long long* counters, hipStream_t st);

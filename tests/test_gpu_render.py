@@ -118,7 +118,7 @@ def test_reflection_and_refraction_vs_oracle():
     assert np.array_equal(ids, oids)
     assert (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow) == \
            (c.rays_primary, c.rays_reflect, c.rays_refract, c.rays_shadow)
-    assert st.rays_refract > 0 and st.rays_reflect > 0 and st.passes > 3
+    assert st.rays_refract > 0 and st.rays_reflect > 0 and st.passes >= 3
     _assert_rgb_close(rgb, orgb)
     g.close(); o.close()
 
