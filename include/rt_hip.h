@@ -209,6 +209,16 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
 int rt_scene_destroy(rt_scene* s);                 /* replaces hw4.cpp:778-783   */
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
 
+/* Traversal algorithm of the trace / render entry points (no counterpart: the reference has one loop).
+ *   RT_TRAVERSAL_STRICT  the reference's visit order, every box and triangle test it performs
+ *   RT_TRAVERSAL_FAST    (default) near-first order + culling of subtrees that cannot hold the winner,
+ *                        ties resolved by the reference's visit rank: same hits, fewer tests
+ * The environment variable RT_TRAVERSAL=strict|fast sets the default of new scenes.                  */
+#define RT_OPT_TRAVERSAL    1
+#define RT_TRAVERSAL_STRICT 0
+#define RT_TRAVERSAL_FAST   1
+int rt_scene_set_option(rt_scene* s, int option, int value);
+
 
 /* Host-only view of what rt_scene_create builds and uploads (no GPU needed):
  * the reference-rule KD-trees (hw4.cpp:330-490) flattened in traversal order.

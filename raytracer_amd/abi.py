@@ -16,6 +16,7 @@ RT_LIGHT_POINT, RT_LIGHT_RECT = 0, 1
 RT_SCENE_CULLING, RT_SCENE_KD_REFERENCE = 1, 2
 RT_RENDER_WHITTED, RT_RENDER_PHOTON = 0, 1
 RT_PMAP_GLOBAL, RT_PMAP_CAUSTIC = 0, 1
+RT_OPT_TRAVERSAL, RT_TRAVERSAL_STRICT, RT_TRAVERSAL_FAST = 1, 0, 1
 
 _f, _i32, _i64, _u8 = C.c_float, C.c_int32, C.c_int64, C.c_uint8
 
@@ -73,7 +74,7 @@ assert ray_dtype.itemsize == 24 and hit_dtype.itemsize == 20 and photon_dtype.it
 # every symbol include/rt_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "rt_init", "rt_last_error", "rt_abi_version",
-    "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_set_option",
     "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit",
@@ -112,6 +113,7 @@ def load():
     L.rt_scene_create.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(vp)]
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_info_get.argtypes = [vp, C.POINTER(rt_scene_info)]
+    L.rt_scene_set_option.argtypes = [vp, i32, i32]
     L.rt_host_flatten.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(vp), C.POINTER(rt_scene_info)]
     L.rt_host_flat_get.argtypes = [vp, i32, vp, i64]
     L.rt_host_flat_get.restype = i64

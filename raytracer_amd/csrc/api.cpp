@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -144,8 +145,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 
     DevSceneView& v = s->view;
     memset(&v, 0, sizeof v);
-    rc = upload(s, flat.nodes, &v.nodes);
-    if (!rc) rc = upload(s, flat.leaf_range, &v.leaf_range);
+    rc = RT_OK;
+    for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.nodes[o], &v.nodes_oct[o]);
+    v.nodes = v.nodes_oct[7];
     if (!rc) rc = upload(s, flat.leaf_tris, &v.leaf_tris);
     if (!rc) rc = upload(s, flat.loose, &v.loose);
     if (!rc) rc = upload(s, flat.prim_normal, &v.prim_normal);
@@ -155,7 +157,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!rc) rc = upload(s, mats, &v.materials);
     if (!rc) rc = upload(s, lights, &v.lights);
     if (rc) { rt_scene_destroy(s); return rc; }
-    v.nnodes = (int32_t)flat.nodes.size();
+    v.nnodes = (int32_t)flat.nodes[7].size();
     v.nloose = (int32_t)flat.loose.size();
     v.nlights = d->nlight;
     v.tol_f = rt_float_above(d->tolerance_depth);
@@ -163,11 +165,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.shadow_bias = d->shadow_bias; v.refract_bias = d->refract_bias;
     s->eps_f = rt_float_above(0.000001);          // `epsilon`, hw4.cpp:18
     s->nprim = d->nprim;
+    if (const char* e = getenv("RT_TRAVERSAL")) s->fast = (strcmp(e, "strict") == 0) ? 0 : 1;
 
     rt_scene_info& inf = s->info;
     memset(&inf, 0, sizeof inf);
     inf.kd_nodes_built = flat.kd_nodes_built; inf.kd_max_depth = flat.kd_max_depth;
-    inf.flat_nodes = (int64_t)flat.nodes.size(); inf.leaf_refs = (int64_t)flat.leaf_tris.size();
+    inf.flat_nodes = (int64_t)flat.nodes[7].size(); inf.leaf_refs = (int64_t)flat.leaf_tris.size();
     inf.ntri = flat.ntri; inf.nsphere = flat.nsphere; inf.nloose = (int64_t)flat.loose.size();
     inf.device_bytes = s->device_bytes;
     *out = s;
@@ -184,6 +187,12 @@ int rt_scene_destroy(rt_scene* s) {
     return RT_OK;
 }
 
+int rt_scene_set_option(rt_scene* s, int option, int value) {
+    if (!s) return rt_fail(RT_E_INVALID, "rt_scene_set_option: NULL scene");
+    if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST)) { s->fast = value; return RT_OK; }
+    return rt_fail(RT_E_INVALID, "rt_scene_set_option: unknown option %d / value %d", option, value);
+}
+
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* info) {
     if (!s || !info) return rt_fail(RT_E_INVALID, "rt_scene_info_get: NULL argument");
     *info = s->info;
@@ -197,7 +206,7 @@ int rt_trace_closest_dev(rt_scene* s, const rt_ray* d_rays, int64_t n, rt_hit* d
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_out))) return rt_fail(RT_E_INVALID, "rt_trace_closest_dev: bad argument");
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
-    hipError_t e = rtk_trace_closest(s->view, d_rays, nullptr, n, s->eps_f, d_out, (hipStream_t)stream);
+    hipError_t e = rtk_trace_closest(s->view, d_rays, nullptr, n, s->eps_f, s->fast, d_out, (hipStream_t)stream);
     if (e != hipSuccess) return rt_hipfail(e, "k_trace_closest");
     return RT_OK;
 }
@@ -212,7 +221,7 @@ int rt_trace_closest(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit* out) {
     if ((rc = s->scratch(1, (size_t)n * sizeof(rt_hit), &dh))) return rc;
     hipError_t e = hipMemcpy(dr, rays, (size_t)n * sizeof(rt_ray), hipMemcpyHostToDevice);
     if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(rays)");
-    e = rtk_trace_closest(s->view, (const rt_ray*)dr, nullptr, n, s->eps_f, (rt_hit*)dh, nullptr);
+    e = rtk_trace_closest(s->view, (const rt_ray*)dr, nullptr, n, s->eps_f, s->fast, (rt_hit*)dh, nullptr);
     if (e != hipSuccess) return rt_hipfail(e, "k_trace_closest");
     e = hipMemcpy(out, dh, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(hits)");
@@ -223,7 +232,7 @@ int rt_trace_any_dev(rt_scene* s, const rt_ray* d_rays, const float* d_tmax, int
     if (!s || n < 0 || (n > 0 && (!d_rays || !d_occ))) return rt_fail(RT_E_INVALID, "rt_trace_any_dev: bad argument");
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
-    hipError_t e = rtk_trace_any(s->view, d_rays, nullptr, d_tmax, n, s->eps_f, d_occ, (hipStream_t)stream);
+    hipError_t e = rtk_trace_any(s->view, d_rays, nullptr, d_tmax, n, s->eps_f, s->fast, d_occ, (hipStream_t)stream);
     if (e != hipSuccess) return rt_hipfail(e, "k_trace_any");
     return RT_OK;
 }
@@ -243,7 +252,7 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, 
         e = hipMemcpy(dt, tmax, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(tmax)");
     }
-    e = rtk_trace_any(s->view, (const rt_ray*)dr, nullptr, (const float*)dt, n, s->eps_f, (uint8_t*)dout, nullptr);
+    e = rtk_trace_any(s->view, (const rt_ray*)dr, nullptr, (const float*)dt, n, s->eps_f, s->fast, (uint8_t*)dout, nullptr);
     if (e != hipSuccess) return rt_hipfail(e, "k_trace_any");
     e = hipMemcpy(occluded, dout, (size_t)n, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return rt_hipfail(e, "hipMemcpy(occluded)");
@@ -280,7 +289,7 @@ extern "C" int rt_host_flatten(const rt_scene_desc* d, rt_host_flat** out, rt_sc
     if (info) {
         memset(info, 0, sizeof *info);
         info->kd_nodes_built = f->flat.kd_nodes_built; info->kd_max_depth = f->flat.kd_max_depth;
-        info->flat_nodes = (int64_t)f->flat.nodes.size(); info->leaf_refs = (int64_t)f->flat.leaf_tris.size();
+        info->flat_nodes = (int64_t)f->flat.nodes[7].size(); info->leaf_refs = (int64_t)f->flat.leaf_tris.size();
         info->ntri = f->flat.ntri; info->nsphere = f->flat.nsphere; info->nloose = (int64_t)f->flat.loose.size();
     }
     *out = f;
@@ -290,18 +299,18 @@ extern "C" int rt_host_flatten(const rt_scene_desc* d, rt_host_flat** out, rt_sc
 extern "C" int64_t rt_host_flat_get(const rt_host_flat* f, int which, void* dst, int64_t cap) {
     if (!f) return rt_fail(RT_E_INVALID, "rt_host_flat_get: NULL");
     const HostFlatScene& h = f->flat;
-    const int64_t nn = (int64_t)h.nodes.size(), nl = (int64_t)h.leaf_tris.size(), no = (int64_t)h.loose.size();
+    const int64_t nn = (int64_t)h.nodes[7].size(), nl = (int64_t)h.leaf_tris.size(), no = (int64_t)h.loose.size();
     const int64_t rows = which <= 4 ? nn : (which == 6 ? no : nl);
     if (which < 0 || which > 7) return rt_fail(RT_E_INVALID, "rt_host_flat_get: bad selector");
     if (!dst) return rows;
     if (cap < rows) return rt_fail(RT_E_INVALID, "rt_host_flat_get: buffer too small");
     for (int64_t i = 0; i < rows; ++i) {
         switch (which) {
-            case 0: memcpy((float*)dst + 6 * i, h.nodes[(size_t)i].lo, 24); break;
-            case 1: ((int32_t*)dst)[i] = h.nodes[(size_t)i].skip; break;
-            case 2: ((int32_t*)dst)[i] = h.nodes[(size_t)i].meta; break;
-            case 3: ((int32_t*)dst)[i] = h.leaf_range[(size_t)i].first; break;
-            case 4: ((int32_t*)dst)[i] = h.leaf_range[(size_t)i].count; break;
+            case 0: memcpy((float*)dst + 6 * i, h.nodes[7][(size_t)i].lo, 24); break;
+            case 1: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].skip; break;
+            case 2: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].meta; break;
+            case 3: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].leaf_first; break;
+            case 4: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].leaf_count; break;
             case 5: ((int32_t*)dst)[i] = h.leaf_tris[(size_t)i].prim; break;
             case 6: ((int32_t*)dst)[i] = h.loose[(size_t)i].prim; break;
             case 7: memcpy((float*)dst + 9 * i, h.leaf_tris[(size_t)i].v0, 36); break;

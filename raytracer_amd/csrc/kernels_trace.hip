@@ -126,8 +126,10 @@ __device__ __forceinline__ bool facing(const DevSceneView& sc, int prim, bool sp
     return (nx * r.dx + ny * r.dy + nz * r.dz) < 0;
 }
 
-struct Closest { float len; int prim; float px, py, pz; };
+struct Closest { float len; int prim; float px, py, pz; int rank; };
 
+// ---------------------------------------------------------------------------
+// STRICT traversal: the reference's visit order and nothing else (no culling).
 // One wave = 64 rays.  ANY: stop at the first accepted hit per lane.
 template <bool ANY>
 __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, bool valid,
@@ -148,9 +150,8 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
         }
         if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
         if (nd.meta & 0x100) {
-            const DevLeafRange lr = sc.leaf_range[i];
-            for (int k = 0; k < lr.count; ++k) {
-                const DevLeafTri* __restrict__ t = sc.leaf_tris + (lr.first + k);   // wave-uniform
+            for (int k = 0; k < nd.leaf_count; ++k) {
+                const DevLeafTri* __restrict__ t = sc.leaf_tris + (nd.leaf_first + k);   // wave-uniform
                 if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
                 if (hit) {
                     float px, py, pz;
@@ -170,7 +171,146 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
         }
         i = i + 1;
     }
-    // primitives outside every tree, in index order (the whole scene for final.cpp)
+}
+
+// ---------------------------------------------------------------------------
+// FAST traversal: same accepted hits, fewer tests.
+//  * the wave walks the layout ordered for its rays' octant (near child first);
+//  * a lane skips a subtree that lies wholly behind its origin, or wholly beyond its current best hit by
+//    more than the subtree's slack: no hit the reference accepts there can win or tie;
+//  * ties (equal len) are resolved by the reference's visit rank (= leaf record index), so the winner is
+//    the one the reference's fixed order would have met first;
+//  * box booleans come from reciprocal-multiply slabs when the decision is clear of rounding doubt, and
+//    from the reference's divisions otherwise; triangle candidates are screened with an approximate
+//    reciprocal and confirmed with the reference's exact sequence.
+struct RayAux {
+    float rx, ry, rz;      // RN(1/d) per axis
+    float dlen;            // |dir|
+    bool plain;            // all direction components finite and non-zero, |dir| in [0.5, 2]: fast paths allowed
+};
+
+__device__ __forceinline__ RayAux ray_aux(const Rayf& r) {
+    RayAux a;
+    a.rx = 1.0f / r.dx; a.ry = 1.0f / r.dy; a.rz = 1.0f / r.dz;
+    a.dlen = sqrt_rn(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
+    const float big = 1e18f, small = 1e-18f;
+    const float ax = __builtin_fabsf(r.dx), ay = __builtin_fabsf(r.dy), az = __builtin_fabsf(r.dz);
+    a.plain = (ax > small && ax < big) && (ay > small && ay < big) && (az > small && az < big) &&
+              (a.dlen > 0.5f && a.dlen < 2.0f) &&
+              (__builtin_fabsf(r.ox) < big) && (__builtin_fabsf(r.oy) < big) && (__builtin_fabsf(r.oz) < big);
+    return a;
+}
+
+// returns the reference's HitTest boolean; enter/exit are slab parameters good to ~1e-6 relative
+__device__ __forceinline__ bool box_fast(const DevNode& n, const Rayf& r, const RayAux& a, float& enter, float& exit) {
+    const float x0 = (n.lo[0] - r.ox) * a.rx, x1 = (n.hi[0] - r.ox) * a.rx;
+    const float y0 = (n.lo[1] - r.oy) * a.ry, y1 = (n.hi[1] - r.oy) * a.ry;
+    const float z0 = (n.lo[2] - r.oz) * a.rz, z1 = (n.hi[2] - r.oz) * a.rz;
+    enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    exit  = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+    const float gap = exit - enter;
+    // each slab value is within 2^-22 relative of the reference's rounded quotient; 2^-19 leaves 8x room
+    const float doubt = 1.9073486e-6f * (__builtin_fabsf(enter) + __builtin_fabsf(exit)) + 1e-30f;
+    if (a.plain && __builtin_fabsf(gap) > doubt) return gap > 0.0f;
+    return box_test(n, r);
+}
+
+template <bool ANY>
+__device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf& r, bool valid,
+                                              float eps_f, float tmax, bool use_tmax,
+                                              Closest& best, bool& occluded) {
+    int fail = valid ? RT_ALIVE : RT_DEAD;
+    const RayAux aux = ray_aux(r);
+    // the wave's layout: octant of its first valid ray (any choice is correct, this one is fastest)
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    const int oct_l = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
+    const int oct = __builtin_amdgcn_readlane(oct_l, __builtin_ctzll(vm));
+    const DevNode* __restrict__ nodes = sc.nodes_oct[oct];
+    const float far_limit = ANY ? (use_tmax ? tmax : 1e9f) : 0.f;
+    const int nn = sc.nnodes;
+    int i = 0;
+    while (i < nn) {
+        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
+        const DevNode nd = nodes[i];                    // wave-uniform address
+        const int depth = nd.meta & 0xff;
+        if (fail >= depth) fail = RT_ALIVE;
+        bool hit = false;
+        if (fail == RT_ALIVE) {
+            float enter, exit;
+            hit = box_fast(nd, r, aux, enter, exit);
+            if (hit && aux.plain) {
+                // lengths along the ray of the slab interval, shrunk/grown by the subtree's slack
+                const float el = enter * aux.dlen, xl = exit * aux.dlen;
+                const float slack = nd.margin * (__builtin_fabsf(el) + __builtin_fabsf(xl)) + 1e-6f;
+                const float limit = ANY ? far_limit : best.len;
+                if (xl + slack < 0.0f || el - slack > limit) hit = false;   // behind the origin / beyond the best hit
+            }
+            if (!hit) fail = depth;
+        }
+        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
+        if (nd.meta & 0x100) {
+            for (int k = 0; k < nd.leaf_count; ++k) {
+                const int rank = nd.leaf_first + k;
+                const DevLeafTri* __restrict__ t = sc.leaf_tris + rank;            // wave-uniform
+                if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+                // --- screening with an approximate reciprocal (same dot products as the exact test) ---
+                const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
+                const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
+                const float pvx = r.dy * e2z - r.dz * e2y;
+                const float pvy = r.dz * e2x - r.dx * e2z;
+                const float pvz = r.dx * e2y - r.dy * e2x;
+                const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+                bool cand = hit && !(__builtin_fabsf(det) < eps_f);
+                const float ri = __builtin_amdgcn_rcpf(det);
+                const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
+                const float du = tx * pvx + ty * pvy + tz * pvz;
+                const float ua = du * ri;
+                cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
+                if (__ballot(cand) == 0ull) continue;
+                const float qx = ty * e1z - tz * e1y;
+                const float qy = tz * e1x - tx * e1z;
+                const float qz = tx * e1y - ty * e1x;
+                const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
+                const float dt = e2x * qx + e2y * qy + e2z * qz;
+                const float va = dv * ri, ta = dt * ri;
+                cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
+                if (__ballot(cand) == 0ull) continue;
+                // --- the reference's exact sequence for the survivors (hw4.cpp:211-230) ---
+                if (cand) {
+                    const float detInv = 1.0f / det;
+                    const float u = du * detInv;
+                    if (!(u < 0 || u > 1.0f)) {
+                        const float v = dv * detInv;
+                        if (!(v < 0 || u + v > 1.0f)) {
+                            const float tt = dt * detInv;
+                            if (!(tt < 0)) {
+                                const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
+                                const float len = dist_to(r, px, py, pz);
+                                if (ANY) {
+                                    if (len < far_limit && len >= sc.tol_f) { occluded = true; fail = RT_DEAD; hit = false; }
+                                } else {
+                                    if ((len < best.len || (len == best.len && rank < best.rank)) && len >= sc.tol_f &&
+                                        (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
+                                        best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                                        best.rank = rank;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        i = i + 1;
+    }
+}
+
+// primitives outside every tree, in index order (the whole scene for final.cpp)
+template <bool ANY>
+__device__ __forceinline__ void loose_prims(const DevSceneView& sc, const Rayf& r, bool valid,
+                                            float eps_f, float tmax, bool use_tmax,
+                                            Closest& best, bool& occluded) {
     bool live = valid && !(ANY && occluded);
     for (int k = 0; k < sc.nloose; ++k) {
         if (ANY) { if (__ballot(live) == 0ull) break; }
@@ -186,6 +326,7 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
         if (ANY) {
             if (len < (use_tmax ? tmax : 1e9f) && len >= sc.tol_f) { occluded = true; live = false; }
         } else {
+            // loose primitives come after every tree in the reference's order: strict < keeps an equal-len tree hit
             if (len < best.len && len >= sc.tol_f && (!sc.culling || facing(sc, l->prim, sph, r, px, py, pz))) {
                 best.len = len; best.prim = l->prim; best.px = px; best.py = py; best.pz = pz;
             }
@@ -205,15 +346,17 @@ __device__ __forceinline__ Rayf load_ray(const rt_ray* __restrict__ rays, int64_
 // active: optional per-ray int32 (ray skipped when < 0), used by the renderer
 extern "C" __global__ void __launch_bounds__(256)
 k_trace_closest(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                int64_t n, float eps_f, rt_hit* __restrict__ out) {
+                int64_t n, float eps_f, int fast, rt_hit* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool inb = i < n;
     const bool valid = inb && (active == nullptr || active[i] >= 0);
     Rayf r = {0, 0, 0, 0, 0, 1};
     if (valid) r = load_ray(rays, i);
-    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f;
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
     bool occ = false;
-    traverse<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
+    if (fast) traverse_fast<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
+    else traverse<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
+    loose_prims<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
     if (inb) {
         float* o = reinterpret_cast<float*>(out + i);
         reinterpret_cast<int32_t*>(o)[0] = best.prim;
@@ -223,16 +366,18 @@ k_trace_closest(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t*
 
 extern "C" __global__ void __launch_bounds__(256)
 k_trace_any(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-            const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
+            const float* __restrict__ tmax, int64_t n, float eps_f, int fast, uint8_t* __restrict__ occluded) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool inb = i < n;
     const bool valid = inb && (active == nullptr || active[i] >= 0);
     Rayf r = {0, 0, 0, 0, 0, 1};
     float tm = 0.f;
     if (valid) { r = load_ray(rays, i); if (tmax) tm = tmax[i]; }
-    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f;
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
     bool occ = false;
-    traverse<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
+    if (fast) traverse_fast<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
+    else traverse<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
+    loose_prims<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
     if (inb) occluded[i] = occ ? 1 : 0;
 }
 
@@ -291,16 +436,16 @@ k_generate_tiled(rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntile
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
-                             float eps_f, rt_hit* d_out, hipStream_t st) {
+                             float eps_f, int fast, rt_hit* d_out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
+    hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, fast, d_out);
     return hipGetLastError();
 }
 
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
-                         int64_t n, float eps_f, uint8_t* d_occ, hipStream_t st) {
+                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+    hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, fast, d_occ);
     return hipGetLastError();
 }
 

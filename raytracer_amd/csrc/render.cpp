@@ -99,14 +99,14 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
         }
         RTCHK(mark());
-        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, (rt_hit*)hits, st), "k_trace_closest");
+        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, s->fast, (rt_hit*)hits, st), "k_trace_closest");
         RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
                                (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, st), "k_shade_flags");
         RTCHK(mark());
         if (L > 0)
-            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, (uint8_t*)occ, st), "k_trace_any");
+            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, s->fast, (uint8_t*)occ, st), "k_trace_any");
         RTCHK(mark());
         HIPCHK(rtk_shade_lights(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, n, (const uint8_t*)occ,
                                 p->ambient_intensity, cam->center, (float*)contrib, d_ctr, st), "k_shade_lights");

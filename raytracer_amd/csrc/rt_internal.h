@@ -14,15 +14,19 @@
 // pushes left then right, so right is popped first), objects in file order
 // (hw4.cpp:808).  Every record carries the index to continue at when its
 // subtree is skipped, so a wave walks the array front to back without a stack.
-struct DevNode {            // 32 B, fetched wave-uniformly (scalar path)
+struct DevNode {            // 48 B, fetched wave-uniformly (scalar path)
     float lo[3];            // center - extend/2.0f  (hw4.cpp:287, precomputed with the same float ops)
     float hi[3];            // center + extend/2.0f
     int32_t skip;           // next node when this subtree is not entered (== index+1 for a leaf)
     int32_t meta;           // bits 0..7 depth, bit 8 leaf
+    float margin;           // relative slack for distance culling of this subtree (fast traversal)
+    int32_t leaf_first;     // leaf: first record in leaf_tris (== reference visit rank of its first triangle)
+    int32_t leaf_count;
+    int32_t pad;
 };
-static_assert(sizeof(DevNode) == 32, "DevNode must be 32 bytes");
+static_assert(sizeof(DevNode) == 48, "DevNode must be 48 bytes");
 
-struct DevLeafRange { int32_t first; int32_t count; };   // into leaf_tris; read only at leaves
+struct DevLeafRange { int32_t first; int32_t count; };
 
 // One triangle reference of a leaf, stored in leaf order (a triangle that is
 // in several leaves is stored several times), so a leaf is one contiguous run.
@@ -69,8 +73,9 @@ struct DevPhoton {          // 32 B, heap order (1-based; slot 0 unused)
 static_assert(sizeof(DevPhoton) == 32, "DevPhoton must be 32 bytes");
 
 struct DevSceneView {       // passed by value to kernels
-    const DevNode* nodes; int32_t nnodes;
-    const DevLeafRange* leaf_range;
+    const DevNode* nodes; int32_t nnodes;      // reference order (= layout 7: right child first everywhere)
+    const DevNode* nodes_oct[8];               // layout o: at a node split on axis a the child on the side the
+                                               // ray comes from is first (bit a of o set = direction negative)
     const DevLeafTri* leaf_tris;
     const DevLoose* loose; int32_t nloose;
     const float* prim_normal;   // [nprim][3] fixed-point normal (triangles)
@@ -87,8 +92,7 @@ struct DevSceneView {       // passed by value to kernels
 // ---------------------------------------------------------------------------
 // host-side flattened scene produced by scene_build.cpp
 struct HostFlatScene {
-    std::vector<DevNode> nodes;
-    std::vector<DevLeafRange> leaf_range;
+    std::vector<DevNode> nodes[8];             // nodes[7] is the reference order
     std::vector<DevLeafTri> leaf_tris;
     std::vector<DevLoose> loose;
     std::vector<float> prim_normal;
@@ -110,9 +114,9 @@ float rt_float_above(double t);
 // kernel launchers (defined in the .hip files)
 #include <hip/hip_runtime_api.h>
 hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
-                             float eps_f, rt_hit* d_out, hipStream_t st);
+                             float eps_f, int fast, rt_hit* d_out, hipStream_t st);
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
-                         int64_t n, float eps_f, uint8_t* d_occ, hipStream_t st);
+                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st);
 hipError_t rtk_generate_linear(const rt_camera& cam, int64_t first, int64_t n, float ox, float oy, rt_ray* d_rays,
                                hipStream_t st);
 hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float ox, float oy,

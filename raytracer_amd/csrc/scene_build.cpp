@@ -26,6 +26,9 @@ struct BuildNode {
     int axis = 0;
     bool leaf = false;
     float model_scale = 2.0f;        // KDNode ctor default (hw4.h:203); only roots get another value
+    // filled while flattening in reference order, reused by the other seven layouts
+    int32_t leaf_first = 0;
+    float margin = 0.f;
 };
 
 struct Builder {
@@ -108,22 +111,17 @@ void fill_tri(float* a, const float* f) {
 struct Flattener {
     const rt_scene_desc* d;
     HostFlatScene* out;
-    // pre-order, right child first: the order in which the reference pops nodes
-    int32_t emit(const BuildNode& n, int depth) {
-        const int32_t me = (int32_t)out->nodes.size();
-        out->nodes.emplace_back();
-        out->leaf_range.push_back(DevLeafRange{0, 0});
-        {
-            DevNode& r = out->nodes[(size_t)me];
-            for (int k = 0; k < 3; ++k) {
-                r.lo[k] = n.center[k] - n.extend[k] / 2.0f;
-                r.hi[k] = n.center[k] + n.extend[k] / 2.0f;
-            }
-            r.meta = depth | (n.leaf ? 0x100 : 0);
-        }
+
+    // Reference order (layout 7): pre-order with the RIGHT child first, the order in which the reference
+    // pops nodes (hw4.cpp:831-836).  Emits the leaf records (their index is the reference's visit rank)
+    // and computes the culling slack of every subtree.
+    int32_t emit_reference(BuildNode& n, int depth) {
+        std::vector<DevNode>& nodes = out->nodes[7];
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        float margin = 0.f;
         if (n.leaf) {
-            DevLeafRange lr{(int32_t)out->leaf_tris.size(), (int32_t)n.prims.size()};
-            out->leaf_range[(size_t)me] = lr;
+            n.leaf_first = (int32_t)out->leaf_tris.size();
             for (int32_t id : n.prims) {
                 DevLeafTri t{};
                 float a[9]; fill_tri(a, d->prims[id].f);
@@ -131,13 +129,48 @@ struct Flattener {
                 t.prim = id;
                 t.flags = ((double)d->materials[d->prim_material[id]].refract > 0.1) ? RT_PF_SKIP_SHADOW : 0;
                 out->leaf_tris.push_back(t);
+                // |edge1|*|edge2| bounds the cancellation in det and in the t numerator
+                const float l1 = std::sqrt(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]);
+                const float l2 = std::sqrt(a[6] * a[6] + a[7] * a[7] + a[8] * a[8]);
+                margin = std::max(margin, l1 * l2);
             }
         } else {
-            emit(*n.right, depth + 1);
-            emit(*n.left, depth + 1);
+            emit_reference(*n.right, depth + 1);
+            emit_reference(*n.left, depth + 1);
+            margin = std::max(n.left->margin, n.right->margin);
         }
-        out->nodes[(size_t)me].skip = (int32_t)out->nodes.size();
+        n.margin = margin;
+        fill(nodes[(size_t)me], n, depth);
+        nodes[(size_t)me].skip = (int32_t)nodes.size();
         return me;
+    }
+
+    // Layout o: the child on the side the ray comes from goes first (bit a of o: direction negative on axis a,
+    // so the larger-coordinate child, `right`, is nearer).
+    void emit_octant(const BuildNode& n, int depth, int o) {
+        std::vector<DevNode>& nodes = out->nodes[o];
+        const size_t me = nodes.size();
+        nodes.emplace_back();
+        if (!n.leaf) {
+            const bool right_first = (o >> n.axis) & 1;
+            emit_octant(right_first ? *n.right : *n.left, depth + 1, o);
+            emit_octant(right_first ? *n.left : *n.right, depth + 1, o);
+        }
+        fill(nodes[me], n, depth);
+        nodes[me].skip = (int32_t)nodes.size();
+    }
+
+    static void fill(DevNode& r, const BuildNode& n, int depth) {
+        for (int k = 0; k < 3; ++k) {
+            r.lo[k] = n.center[k] - n.extend[k] / 2.0f;
+            r.hi[k] = n.center[k] + n.extend[k] / 2.0f;
+        }
+        r.meta = depth | (n.leaf ? 0x100 : 0);
+        // 4x safety on the bound, plus a floor that covers the rounding of the slab arithmetic itself
+        r.margin = 4.0f * n.margin + 1e-4f;
+        r.leaf_first = n.leaf ? n.leaf_first : 0;
+        r.leaf_count = n.leaf ? (int32_t)n.prims.size() : 0;
+        r.pad = 0;
     }
 };
 
@@ -178,8 +211,9 @@ int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string*
         out->kd_max_depth = std::max(out->kd_max_depth, b.max_depth);
         if (b.max_depth + 1 > 250) { *err = "KD-tree deeper than 250 levels"; return RT_E_LIMIT; }
         Flattener f{d, out};
-        f.emit(root, 0);
-        if (out->nodes.size() > (size_t)INT32_MAX / 2 || out->leaf_tris.size() > (size_t)INT32_MAX / 2) {
+        f.emit_reference(root, 0);
+        for (int o = 0; o < 7; ++o) f.emit_octant(root, 0, o);
+        if (out->nodes[7].size() > (size_t)INT32_MAX / 2 || out->leaf_tris.size() > (size_t)INT32_MAX / 2) {
             *err = "scene exceeds 2^30 nodes or leaf references"; return RT_E_LIMIT;
         }
     }

@@ -113,6 +113,11 @@ class Scene:
         except Exception:
             pass
 
+    def set_traversal(self, mode):
+        """"strict" (reference order, no culling) or "fast" (default)."""
+        abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_TRAVERSAL,
+                                             abi.RT_TRAVERSAL_STRICT if mode == "strict" else abi.RT_TRAVERSAL_FAST))
+
     def info(self):
         i = abi.rt_scene_info()
         abi.check(self.L.rt_scene_info_get(self.h, C.byref(i)))

@@ -29,9 +29,10 @@ def _assert_rgb_close(got, want):
     return int((d > 0).sum())
 
 
-@pytest.fixture(scope="module")
-def gscene(monkey_sd):
+@pytest.fixture(scope="module", params=["fast", "strict"])
+def gscene(monkey_sd, request):
     s = host.Scene(monkey_sd)
+    s.set_traversal(request.param)
     yield s
     s.close()
 

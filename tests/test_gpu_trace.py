@@ -47,9 +47,10 @@ def _assert_hits_equal(g, o):
     assert np.all(g["len"][~hit] == np.float32(1e9))
 
 
-@pytest.fixture(scope="module")
-def monkey(monkey_sd):
+@pytest.fixture(scope="module", params=["fast", "strict"])
+def monkey(monkey_sd, request):
     g = host.Scene(monkey_sd)
+    g.set_traversal(request.param)
     o = ol.OracleScene(monkey_sd)
     yield g, o
     g.close(); o.close()
@@ -114,8 +115,64 @@ def test_final_scene_brute_force_with_spheres_and_culling():
     import os
     sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
     g = host.Scene(sd); o = ol.OracleScene(sd)
+    assert g.info().nloose == 14 and g.info().flat_nodes == 0
     rays = np.concatenate([_primary_rays(sd, 96, 96), _random_rays(6000, 9, box=0.45)])
     _assert_hits_equal(g.trace_closest(rays), o.trace_closest(rays))
     tmax = np.random.default_rng(2).uniform(0.05, 1.5, rays.shape[0]).astype(np.float32)
     assert np.array_equal(g.trace_any(rays, tmax), o.trace_any(rays, tmax))
     g.close(); o.close()
+
+
+def _soup_scene(n, seed, nobj=3, big_floor=True):
+    """random triangle soup in several objects, plus two large floor triangles (large |e1||e2| slack)."""
+    from raytracer_amd.scene import SceneData
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-0.45, 0.45, (n, 1, 3)); v = (c + rng.normal(scale=0.03, size=(n, 3, 3))).astype(np.float32)
+    v[..., 2] += 0.6
+    if big_floor:
+        v[0] = [[-2, -0.5, -1], [-2, -0.5, 3], [2, -0.5, 3]]; v[1] = [[-2, -0.5, -1], [2, -0.5, 3], [2, -0.5, -1]]
+    nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]).astype(np.float32)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+    prims = np.concatenate([v.reshape(n, 9), nrm], axis=1).astype(np.float32)
+    cuts = np.linspace(0, n, nobj + 1).astype(np.int64)
+    return SceneData(prims=prims, prim_type=np.zeros(n, np.uint8), prim_material=np.zeros(n, np.int32),
+                     materials=np.array([[1, 1, 1, 1, 0, 0, 1, 0, 0, 1]], np.float32), obj_first=cuts[:-1],
+                     obj_count=np.diff(cuts), lights=[dict(pos=(1, 2, -1))], eye=np.array([0, 0, -1], np.float32),
+                     view=np.array([0, 0, 1], np.float32), fov=45.0, resx=64, resy=64)
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+def test_triangle_soup_all_octants(mode):
+    """3 000 overlapping triangles in 3 objects: rays from every octant, inside and outside the geometry."""
+    sd = _soup_scene(3000, 31)
+    g = host.Scene(sd); g.set_traversal(mode)
+    o = ol.OracleScene(sd)
+    rays = np.concatenate([_random_rays(30000, 41, box=0.7), _primary_rays(sd, 128, 128), _edge_rays()])
+    # unnormalised and tiny/huge directions take the guarded path
+    extra = _random_rays(2000, 43); extra[:, 3:6] *= np.float32(7.5); extra[::3, 3:6] *= np.float32(1e-3)
+    rays = np.concatenate([rays, extra])
+    _assert_hits_equal(g.trace_closest(rays), o.trace_closest(rays))
+    assert np.array_equal(g.trace_any(rays), o.trace_any(rays))
+    tmax = np.random.default_rng(3).uniform(0.02, 1.5, rays.shape[0]).astype(np.float32)
+    assert np.array_equal(g.trace_any(rays, tmax), o.trace_any(rays, tmax))
+    g.close(); o.close()
+
+
+def test_exact_ties_resolve_like_the_reference_order():
+    """coplanar duplicated triangles in different objects: equal len, the reference keeps the first visited."""
+    from raytracer_amd.scene import SceneData
+    base = _soup_scene(400, 77, nobj=1, big_floor=False)
+    prims = np.concatenate([base.prims, base.prims[::-1]])           # second object: same triangles, reversed order
+    n = prims.shape[0]
+    sd = SceneData(prims=prims, prim_type=np.zeros(n, np.uint8), prim_material=np.zeros(n, np.int32),
+                   materials=base.materials, obj_first=np.array([0, 400], np.int64), obj_count=np.array([400, 400], np.int64),
+                   lights=base.lights, eye=base.eye, view=base.view, fov=45.0, resx=64, resy=64)
+    o = ol.OracleScene(sd)
+    rays = np.concatenate([_primary_rays(sd, 160, 160), _random_rays(20000, 5, box=0.6)])
+    want = o.trace_closest(rays)
+    assert (want["prim"] >= 0).sum() > 5000 and (want["prim"][want["prim"] >= 0] < 400).all()   # first object wins every tie
+    for mode in ("fast", "strict"):
+        g = host.Scene(sd); g.set_traversal(mode)
+        _assert_hits_equal(g.trace_closest(rays), want)
+        g.close()
+    o.close()
