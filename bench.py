@@ -69,28 +69,28 @@ def rank_pixel_index(resx, resy, rank, nranks, tile=TILE):
     return np.concatenate(out) if out else np.zeros(0, np.int64)
 
 
-def algorithmic_bytes_per_ray(sd, sample_res):
-    """per ray = 32 B ray in + 32 B x box tests + 36 B x triangle tests + 4 B x leaf index
-    reads + 20 B hit out, with the test counts THIS kernel's algorithm performs per ray (the reference
-    box-tests every entered node twice, hw4.cpp:825; the kernel tests it once), counted by the CPU
-    oracle on a strided sample of the frame."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as ol
-    from raytracer_amd import host
-    o = ol.OracleScene(sd)
-    cam = ol.oracle_camera(sd.eye, sd.view, sd.fov, *sample_res)
-    t0 = time.perf_counter()
-    o.render_whitted(cam, host.default_params("hw4", primary_only=1))
-    dt = time.perf_counter() - t0
-    c = o.counters()
-    rays = c.rays_traced
-    box = (c.box_tests - c.node_pops) / rays
-    tri = c.tri_tests / rays
-    leaf = c.leaf_refs_read / rays
-    o.close()
-    per_ray = 32 + 32 * box + 36 * tri + 4 * leaf + 20
-    return dict(bytes_per_ray=per_ray, box_tests_per_ray=box, tri_tests_per_ray=tri, rays=rays, seconds=dt,
-                ref_box_tests_per_ray=c.box_tests / rays)
+def algorithmic_bytes_per_ray(gs, cam, params, sp):
+    """per ray = 32 B ray in + 32 B x box tests + 36 B x triangle tests + 20 B hit out, with the
+    test counts THIS kernel's algorithm performs per ray.  The counts come from one extra, untimed frame
+    rendered with rt_params.count_work = 1: the same traversal code instantiated with per-lane counters
+    (k_trace_work), on exactly the rays of the bench frame.  (The leaf-index term of SURVEY's formula is 0:
+    leaf triangles are stored in leaf order, there is no index indirection.)"""
+    from raytracer_amd import abi
+    import copy
+    import torch
+    p2 = abi.rt_params.from_buffer_copy(bytes(params))
+    p2.count_work = 1
+    st = abi.rt_stats()
+    frame = torch.zeros(cam.resx * cam.resy * 3, dtype=torch.uint8, device="cuda")
+    abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p2), frame.data_ptr(), None, C.byref(st), sp))
+    rays = st.rays_primary + st.rays_reflect + st.rays_refract
+    box, tri, exact, fetch = (x / rays for x in st.closest_work)
+    srays = max(1, st.rays_shadow)
+    abox, atri, aexact, afetch = (x / srays for x in st.any_work)
+    return dict(bytes_per_ray=32 + 32 * box + 36 * tri + 20, box_tests_per_ray=box, tri_tests_per_ray=tri,
+                exact_tri_tests_per_ray=exact, record_fetches_per_ray=fetch, rays=rays,
+                any_bytes_per_ray=32 + 32 * abox + 36 * atri + 1, any_box_tests_per_ray=abox,
+                any_tri_tests_per_ray=atri)
 
 
 def cpu_baseline(sd, res):
@@ -326,7 +326,7 @@ def main():
                           "frame": [resx, resy], "rays_per_step": total_rays / args.steps,
                           "parallelism": f"tiles{TILE}x{TILE} round-robin over {n} GPU(s), scene replicated, gather to rank 0"}}
         # roofline of the dominant kernel (k_trace_closest): algorithmic bytes / HIP-event time
-        alg = algorithmic_bytes_per_ray(sd, (480, 270))
+        alg = algorithmic_bytes_per_ray(gs, cam, params, sp)
         launches = max(1, tot["closest_launches"])
         rays_per_launch = tot["closest_rays"] / launches
         avg_ms = tot["closest_ms"] / launches
@@ -342,6 +342,8 @@ def main():
                            "traffic": traffic, "kernel": "k_trace_closest", "avg_launch_ms": avg_ms,
                            "rays_per_launch": rays_per_launch, "bytes_per_ray": alg["bytes_per_ray"],
                            "box_tests_per_ray": alg["box_tests_per_ray"], "tri_tests_per_ray": alg["tri_tests_per_ray"],
+                           "exact_tri_tests_per_ray": alg["exact_tri_tests_per_ray"],
+                           "any_hit_bytes_per_ray": alg["any_bytes_per_ray"],
                            "any_hit_ms_per_step": tot["any_ms"] / args.steps,
                            "note": "scene (4 KB nodes + 100 KB leaf triangles) is cache resident: algorithmic bytes are served "
                                    "by the scalar cache / L2, not HBM; see DESIGN.md"}

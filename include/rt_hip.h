@@ -165,6 +165,8 @@ typedef struct rt_params {
     float   knn_radius_caustic; /* 0.1                                           */
     int32_t irradiance_max_depth; /* IRRADIANCE_MAX_DEPTH 3                      */
     int32_t aa_taps;            /* KERNEL_SIZE 6 (0 = one centre sample)         */
+    int32_t count_work;         /* 1: also run the counting traversal on every pass and fill
+                                   rt_stats.closest_work / any_work (measurement only, slow) */
     uint64_t seed;              /* counter-based RNG key (build-defined)         */
 } rt_params;
 
@@ -178,6 +180,8 @@ typedef struct rt_stats {
     double  trace_closest_ms;   /* sum over passes of the closest-hit kernel's time (HIP events)     */
     double  trace_any_ms;       /* sum over passes of the any-hit (shadow) kernel's time             */
     int64_t trace_closest_launches, trace_any_launches;
+    int64_t closest_work[4];    /* rt_trace_work_dev's four counters over all closest-hit passes (count_work) */
+    int64_t any_work[4];        /* the same over all any-hit passes                                          */
 } rt_stats;
 
 /* 40-byte photon record, field order of PhotonStruct photon.h:133-141.          */
@@ -257,6 +261,15 @@ int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n,
                  uint8_t* occluded);
 int rt_trace_any_dev(rt_scene* s, const rt_ray* d_rays, const float* d_tmax,
                      int64_t n, uint8_t* d_occluded, void* hip_stream);
+
+/* Measurement only (no counterpart; the reference keeps `totalIntersectionCheck`/`checkTime`,
+ * hw4.cpp:52-54,843,1022): runs the traversal of rt_trace_closest (any == 0) or rt_trace_any (any != 0)
+ * in the scene's current traversal mode with work counters instead of results.  counts[0] box tests,
+ * counts[1] triangle records read by a ray inside a leaf (screened or exactly tested), counts[2] exact
+ * reference-sequence primitive tests, counts[3] record fetches summed over rays.  d_rays is a device
+ * pointer; the call synchronises the stream.                                                          */
+int rt_trace_work_dev(rt_scene* s, const rt_ray* d_rays, const float* d_tmax, int64_t n, int any,
+                      int64_t counts[4], void* hip_stream);
 
 /* ---- photon map ---------------------------------------------------------- */
 

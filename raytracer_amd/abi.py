@@ -54,14 +54,15 @@ class rt_params(C.Structure):
                 ("start_nr", _f), ("primary_only", _i32), ("tile_size", _i32), ("tile_rank", _i32),
                 ("tile_nranks", _i32), ("gather_samples", _i32), ("knn_k", _i32), ("knn_radius_global", _f),
                 ("knn_radius_caustic", _f), ("irradiance_max_depth", _i32), ("aa_taps", _i32),
-                ("seed", C.c_uint64)]
+                ("count_work", _i32), ("seed", C.c_uint64)]
 
 
 class rt_stats(C.Structure):
     _fields_ = [("rays_primary", _i64), ("rays_shadow", _i64), ("rays_reflect", _i64), ("rays_refract", _i64),
                 ("rays_gather", _i64), ("knn_lookups", _i64), ("passes", _i64), ("kernel_ms", C.c_double),
                 ("trace_closest_ms", C.c_double), ("trace_any_ms", C.c_double),
-                ("trace_closest_launches", _i64), ("trace_any_launches", _i64)]
+                ("trace_closest_launches", _i64), ("trace_any_launches", _i64),
+                ("closest_work", _i64 * 4), ("any_work", _i64 * 4)]
 
 
 # numpy views of the POD records
@@ -76,7 +77,7 @@ SYMBOLS = [
     "rt_init", "rt_last_error", "rt_abi_version",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_set_option",
     "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
-    "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev",
+    "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_irradiance", "rt_photon_irradiance_dev",
     "rt_render", "rt_render_dev", "rt_generate_primary_dev",
@@ -124,6 +125,7 @@ def load():
     L.rt_trace_closest_dev.argtypes = [vp, vp, i64, vp, vp]
     L.rt_trace_any.argtypes = [vp, vp, vp, i64, vp]
     L.rt_trace_any_dev.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.rt_trace_work_dev.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.rt_generate_primary_dev.argtypes = [vp, C.POINTER(rt_camera), i64, i64, C.c_float, C.c_float, vp, vp]
     if hasattr(L, "rt_render"):
         L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, vp, C.POINTER(rt_stats)]

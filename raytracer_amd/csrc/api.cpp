@@ -237,6 +237,26 @@ int rt_trace_any_dev(rt_scene* s, const rt_ray* d_rays, const float* d_tmax, int
     return RT_OK;
 }
 
+int rt_trace_work_dev(rt_scene* s, const rt_ray* d_rays, const float* d_tmax, int64_t n, int any, int64_t counts[4],
+                      void* stream) {
+    if (!s || n < 0 || !counts || (n > 0 && !d_rays)) return rt_fail(RT_E_INVALID, "rt_trace_work_dev: bad argument");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    void* dc; int rc;
+    if ((rc = s->scratch(2, 4 * sizeof(unsigned long long), &dc))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dc, 0, 4 * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return rt_hipfail(e, "hipMemsetAsync(counters)");
+    e = rtk_trace_work(s->view, d_rays, nullptr, d_tmax, n, s->eps_f, s->fast, any, (unsigned long long*)dc, st);
+    if (e != hipSuccess) return rt_hipfail(e, "k_trace_work");
+    unsigned long long h[4];
+    e = hipMemcpyAsync(h, dc, sizeof h, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return rt_hipfail(e, "read counters");
+    for (int i = 0; i < 4; ++i) counts[i] = (int64_t)h[i];
+    return RT_OK;
+}
+
 int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, uint8_t* occluded) {
     if (!s || n < 0 || (n > 0 && (!rays || !occluded))) return rt_fail(RT_E_INVALID, "rt_trace_any: bad argument");
     if (n == 0) return RT_OK;

@@ -128,13 +128,17 @@ __device__ __forceinline__ bool facing(const DevSceneView& sc, int prim, bool sp
 
 struct Closest { float len; int prim; float px, py, pz; int rank; };
 
+// per-lane work counters of the measurement-only kernel k_trace_work (bench.py's algorithmic bytes)
+struct Work { unsigned box, tri, exact, fetch; };
+
+
 // ---------------------------------------------------------------------------
 // STRICT traversal: the reference's visit order and nothing else (no culling).
 // One wave = 64 rays.  ANY: stop at the first accepted hit per lane.
-template <bool ANY>
+template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, bool valid,
                                          float eps_f, float tmax, bool use_tmax,
-                                         Closest& best, bool& occluded) {
+                                         Closest& best, bool& occluded, Work* w = nullptr) {
     int fail = valid ? RT_ALIVE : RT_DEAD;
     const int nn = sc.nnodes;
     int i = 0;
@@ -144,7 +148,9 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
         const int depth = nd.meta & 0xff;
         if (fail >= depth) fail = RT_ALIVE;             // left the subtree this lane had failed in
         bool hit = false;
+        if (COUNT) w->fetch += 1;
         if (fail == RT_ALIVE) {
+            if (COUNT) w->box += 1;
             hit = box_test(nd, r);
             if (!hit) fail = depth;
         }
@@ -153,8 +159,10 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
             for (int k = 0; k < nd.leaf_count; ++k) {
                 const DevLeafTri* __restrict__ t = sc.leaf_tris + (nd.leaf_first + k);   // wave-uniform
                 if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+                if (COUNT) w->fetch += 1;
                 if (hit) {
                     float px, py, pz;
+                    if (COUNT) { w->tri += 1; w->exact += 1; }
                     if (tri_test(t->v0, r, eps_f, px, py, pz)) {
                         const float len = dist_to(r, px, py, pz);
                         if (ANY) {
@@ -215,10 +223,10 @@ __device__ __forceinline__ bool box_fast(const DevNode& n, const Rayf& r, const 
     return box_test(n, r);
 }
 
-template <bool ANY>
+template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf& r, bool valid,
                                               float eps_f, float tmax, bool use_tmax,
-                                              Closest& best, bool& occluded) {
+                                              Closest& best, bool& occluded, Work* w = nullptr) {
     int fail = valid ? RT_ALIVE : RT_DEAD;
     const RayAux aux = ray_aux(r);
     // the wave's layout: octant of its first valid ray (any choice is correct, this one is fastest)
@@ -236,8 +244,10 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
         const int depth = nd.meta & 0xff;
         if (fail >= depth) fail = RT_ALIVE;
         bool hit = false;
+        if (COUNT) w->fetch += 1;
         if (fail == RT_ALIVE) {
             float enter, exit;
+            if (COUNT) w->box += 1;
             hit = box_fast(nd, r, aux, enter, exit);
             if (hit && aux.plain) {
                 // lengths along the ray of the slab interval, shrunk/grown by the subtree's slack
@@ -261,6 +271,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
                 const float pvy = r.dz * e2x - r.dx * e2z;
                 const float pvz = r.dx * e2y - r.dy * e2x;
                 const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+                if (COUNT) { w->fetch += 1; if (hit) w->tri += 1; }
                 bool cand = hit && !(__builtin_fabsf(det) < eps_f);
                 const float ri = __builtin_amdgcn_rcpf(det);
                 const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
@@ -278,6 +289,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
                 if (__ballot(cand) == 0ull) continue;
                 // --- the reference's exact sequence for the survivors (hw4.cpp:211-230) ---
                 if (cand) {
+                    if (COUNT) w->exact += 1;
                     const float detInv = 1.0f / det;
                     const float u = du * detInv;
                     if (!(u < 0 || u > 1.0f)) {
@@ -307,17 +319,19 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
 }
 
 // primitives outside every tree, in index order (the whole scene for final.cpp)
-template <bool ANY>
+template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void loose_prims(const DevSceneView& sc, const Rayf& r, bool valid,
                                             float eps_f, float tmax, bool use_tmax,
-                                            Closest& best, bool& occluded) {
+                                            Closest& best, bool& occluded, Work* w = nullptr) {
     bool live = valid && !(ANY && occluded);
     for (int k = 0; k < sc.nloose; ++k) {
         if (ANY) { if (__ballot(live) == 0ull) break; }
         const DevLoose* __restrict__ l = sc.loose + k;                              // wave-uniform
         const int flags = l->flags;
         if (ANY && use_tmax && (flags & RT_PF_SKIP_SHADOW)) continue;
+        if (COUNT) w->fetch += 1;
         if (!live) continue;
+        if (COUNT) { w->tri += 1; w->exact += 1; }
         float px, py, pz;
         const bool sph = (flags & RT_PF_SPHERE) != 0;
         const bool b = sph ? sphere_test(l->a, r, px, py, pz) : tri_test(l->a, r, eps_f, px, py, pz);
@@ -379,6 +393,42 @@ k_trace_any(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __r
     else traverse<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
     loose_prims<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
     if (inb) occluded[i] = occ ? 1 : 0;
+}
+
+// Measurement only (bench.py, tests): the same traversal with per-lane work counters.  out4[0] box tests,
+// [1] triangle records read by a lane that was inside the leaf (screening or exact), [2] exact
+// reference-sequence triangle tests, [3] node / triangle record fetches summed over lanes (a wave-uniform
+// fetch counts 64).  One vector atomic per wave and counter at the end; no results are written.
+extern "C" __global__ void __launch_bounds__(256)
+k_trace_work(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+             const float* __restrict__ tmax, int64_t n, float eps_f, int fast, int any,
+             unsigned long long* __restrict__ out4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    const bool valid = inb && (active == nullptr || active[i] >= 0);
+    Rayf r = {0, 0, 0, 0, 0, 1};
+    float tm = 0.f;
+    if (valid) { r = load_ray(rays, i); if (tmax) tm = tmax[i]; }
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+    bool occ = false;
+    Work w = {0, 0, 0, 0};
+    if (any) {
+        if (fast) traverse_fast<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
+        else traverse<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
+        loose_prims<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
+    } else {
+        if (fast) traverse_fast<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
+        else traverse<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
+        loose_prims<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
+    }
+    unsigned v[4] = {w.box, w.tri, w.exact, valid ? w.fetch : 0u};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        unsigned long long x = v[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(out4 + c, x);
+    }
 }
 
 // Camera::GetPixelCenter + normalize, hw4.cpp:268-276, 1053-1056.
@@ -446,6 +496,14 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
                          int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, fast, d_occ);
+    return hipGetLastError();
+}
+
+hipError_t rtk_trace_work(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
+                          int64_t n, float eps_f, int fast, int any, unsigned long long* d_out4, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_trace_work, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, fast,
+                       any, d_out4);
     return hipGetLastError();
 }
 

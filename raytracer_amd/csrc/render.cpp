@@ -11,9 +11,9 @@ namespace {
 
 enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
-    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS
+    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK
 };
-static_assert(S_PAIRS < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_WORK < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -64,6 +64,13 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     uint32_t* d_total = (uint32_t*)(d_ctr + 8);
     HIPCHK(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long) + 16, st), "memset counters");
 
+    unsigned long long* d_work = nullptr;       // [0..3] closest, [4..7] any (count_work)
+    if (stats && p->count_work) {
+        void* w; RTCHK(s->scratch(S_WORK, 8 * sizeof(unsigned long long), &w));
+        HIPCHK(hipMemsetAsync(w, 0, 8 * sizeof(unsigned long long), st), "memset work counters");
+        d_work = (unsigned long long*)w;
+    }
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;      // per-kernel event pairs: [closest begin, closest end, any begin, any end] per pass
     auto mark = [&](void) -> int {
@@ -108,6 +115,12 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         if (L > 0)
             HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, s->fast, (uint8_t*)occ, st), "k_trace_any");
         RTCHK(mark());
+        if (d_work) {
+            HIPCHK(rtk_trace_work(s->view, q_rays, q_pix, nullptr, n, s->eps_f, s->fast, 0, d_work, st), "k_trace_work");
+            if (L > 0)
+                HIPCHK(rtk_trace_work(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, s->fast, 1,
+                                      d_work + 4, st), "k_trace_work");
+        }
         HIPCHK(rtk_shade_lights(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, n, (const uint8_t*)occ,
                                 p->ambient_intensity, cam->center, (float*)contrib, d_ctr, st), "k_shade_lights");
         HIPCHK(rtk_accumulate(q_pix, (const float*)contrib, n, (float*)accum, st), "k_accumulate");
@@ -139,8 +152,9 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     HIPCHK(rtk_finalize((const int32_t*)pix0, n0, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8, st), "k_finalize");
     if (stats) {
         HIPCHK(hipEventRecord(ev1, st), "event");
-        unsigned long long h[8];
+        unsigned long long h[8], hw[8] = {};
         HIPCHK(hipMemcpyAsync(h, d_ctr, sizeof h, hipMemcpyDeviceToHost, st), "read counters");
+        if (d_work) HIPCHK(hipMemcpyAsync(hw, d_work, sizeof hw, hipMemcpyDeviceToHost, st), "read work counters");
         HIPCHK(hipStreamSynchronize(st), "sync");
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1), "event time");
@@ -151,6 +165,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         stats->rays_shadow = (int64_t)h[1] * L;      // one shadow ray per hit and light (hw4.cpp:929-931)
         stats->passes = passes;
         stats->kernel_ms = ms;
+        for (int c = 0; c < 4; ++c) { stats->closest_work[c] = (int64_t)hw[c]; stats->any_work[c] = (int64_t)hw[4 + c]; }
         for (size_t i = 0; i + 3 < kev.size(); i += 4) {
             float a = 0.f, b = 0.f;
             HIPCHK(hipEventElapsedTime(&a, kev[i], kev[i + 1]), "event time");

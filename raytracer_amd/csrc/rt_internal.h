@@ -117,6 +117,8 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
                              float eps_f, int fast, rt_hit* d_out, hipStream_t st);
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
                          int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st);
+hipError_t rtk_trace_work(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
+                          int64_t n, float eps_f, int fast, int any, unsigned long long* d_out4, hipStream_t st);
 hipError_t rtk_generate_linear(const rt_camera& cam, int64_t first, int64_t n, float ox, float oy, rt_ray* d_rays,
                                hipStream_t st);
 hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float ox, float oy,

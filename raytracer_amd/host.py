@@ -62,6 +62,7 @@ def default_params(flavour="hw4", **kw):
     p.background[:] = [0.0, 0.0, 0.0]
     p.start_nr = 1.0 if flavour == "hw4" else 2.4
     p.primary_only = 0
+    p.count_work = 0
     p.tile_size = 0; p.tile_rank = 0; p.tile_nranks = 1
     p.gather_samples = 50; p.knn_k = 100; p.knn_radius_global = 1.0; p.knn_radius_caustic = 0.1
     p.irradiance_max_depth = 3; p.aa_taps = 0 if flavour == "hw4" else 6
@@ -137,6 +138,13 @@ class Scene:
         abi.check(self.L.rt_trace_any(self.h, rays.ctypes.data, None if t is None else t.ctypes.data,
                                       rays.shape[0], out.ctypes.data))
         return out
+
+    def trace_work(self, d_rays_ptr, n, any_hit=False, d_tmax_ptr=None, stream_ptr=None):
+        """work counters of the traversal on device-resident rays: (box tests, triangle records read,
+        exact tests, record fetches) -- measurement only."""
+        c = (C.c_int64 * 4)()
+        abi.check(self.L.rt_trace_work_dev(self.h, d_rays_ptr, d_tmax_ptr, n, 1 if any_hit else 0, c, stream_ptr))
+        return tuple(int(x) for x in c)
 
     def render(self, cam, params, want_ids=False):
         n = cam.resx * cam.resy

@@ -33,12 +33,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(H, s)
 
 
-def test_struct_sizes_match_header():
-    # sizes printed by a C program that includes include/rt_hip.h (x86-64 SysV)
-    got = [C.sizeof(x) for x in (abi.rt_material, abi.rt_camera, abi.rt_light, abi.rt_scene_desc, abi.rt_scene_info,
-                                 abi.rt_params, abi.rt_stats)]
-    assert got == [40, 92, 72, 120, 64, 80, 96] and abi.photon_dtype.itemsize == 40
-    assert abi.ray_dtype.itemsize == 24 and abi.hit_dtype.itemsize == 20
+def test_struct_sizes_match_header(tmp_path):
+    # sizes printed by a C program that includes include/rt_hip.h (x86-64 SysV), compiled here with gcc
+    import subprocess
+    names = ["rt_material", "rt_camera", "rt_light", "rt_scene_desc", "rt_scene_info", "rt_params", "rt_stats",
+             "rt_photon", "rt_ray", "rt_hit", "rt_prim"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "rt_hip.h"\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    want = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    got = [C.sizeof(getattr(abi, n)) for n in names[:7]] + [abi.photon_dtype.itemsize, abi.ray_dtype.itemsize,
+                                                            abi.hit_dtype.itemsize, 48]
+    assert got == want
 
 
 def test_product_has_no_cpu_path_and_says_so(monkey_sd):
