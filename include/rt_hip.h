@@ -282,17 +282,34 @@ int rt_photonmap_upload(rt_scene* s, int which, const rt_photon* heap_order, int
 /* Replaces PhotonMap::balance (photon.cpp:133-254) for callers that hold an
  * unbalanced array photons[1..n] (as AddPhoton leaves it, photon.cpp:835-885):
  * balances on the host exactly as the reference does, writes the heap order
- * back into `photons` and uploads it.                                          */
-int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n);
+ * (scaled, see below) back into `photons` and uploads it.                       */
+int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, float power_scale);
+/* power_scale: ScalePhotonPower(power_scale, 0, n) after the balance as final.cpp:1126 does it, i.e.
+ * heap slots 0..n-1 are scaled and slot n keeps its power (photon.cpp:826-833); 1.0f = leave.   */
 
-/* Replaces the emission loops final.cpp:1057-1119 + PhotonTrace /
- * PhotonTraceCaustics (photon.cpp:445-710) with a counter-based RNG keyed by
- * the global emission index: emits emission indices [first, first+count) on
- * the GPU and returns the photons they stored, in emission order, in `out`
- * (capacity `cap`, *nstored receives the number written).  Sharding emission
- * over ranks = giving each rank a disjoint index range.                        */
-int rt_photonmap_emit(rt_scene* s, int which, int64_t first, int64_t count,
-                      uint64_t seed, rt_photon* out, int64_t cap, int64_t* nstored);
+/* Parameters of one emission loop of PhotonMappingImageSynthesis (final.cpp:1053-1123).           */
+typedef struct rt_emit_params {
+    int32_t  which;              /* RT_PMAP_GLOBAL: PhotonTrace (photon.cpp:445-568);
+                                    RT_PMAP_CAUSTIC: PhotonTraceCaustics (:570-710)              */
+    int32_t  light;              /* index of the emitting (rect) light, final.cpp:1053            */
+    float    power[3];           /* photon colour at the light: 3,3,3 (:1078) / .2,.2,.2 (:1115)  */
+    float    start_nr;           /* 2.40, final.cpp:1080                                          */
+    int32_t  max_depth;          /* PHOTON_TRACE_MAX_DEPTH 6, parameter.h:26                      */
+    int32_t  ncaustic_sphere;    /* causticMeshes (final.cpp:754-758): proxy spheres a caustic    */
+    float    caustic_sphere[4][4]; /*   photon must be aimed at: centre xyz, radius               */
+    float    caustic_floor_y;    /* -0.3: caustic photons are stored only at y <= this (:697)     */
+    uint64_t seed;               /* key of the counter-based RNG                                  */
+} rt_emit_params;
+
+/* Replaces the emission loops final.cpp:1057-1119 + PhotonTrace / PhotonTraceCaustics
+ * (photon.cpp:445-710) + AddPhoton (:835-885).  The reference draws from one serial engine; here
+ * every emission index has its own counter-based random stream, so emission indices
+ * [first, first+count) can be traced in parallel and on any rank: the photons they store are
+ * returned in emission order in out[0..*nstored) (capacity cap; *nstored may exceed cap, then
+ * only the first cap were written).  `plane` is 0; the array is what AddPhoton leaves
+ * behind, ready for rt_photonmap_build.                                                         */
+int rt_photonmap_emit(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count,
+                      rt_photon* out, int64_t cap, int64_t* nstored);
 
 /* Replaces PhotonMap::LocatePhoton (photon.cpp:53-131): for each query the k
  * nearest photons within maxDist.  idx: [q][k] heap-array indices (1-based as

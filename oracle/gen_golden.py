@@ -201,14 +201,105 @@ def gen_photon():
     print("photon golden: N", N, "Q", Q, "mean found r=0.1:", out["found_r01"].mean())
 
 
+def final_emit_params(which, seed=7):
+    """the two emission loops of final.cpp:1053-1123 as rt_emit_params"""
+    e = abi.rt_emit_params(); e.which = which; e.light = 0
+    e.power[:] = [3.0, 3.0, 3.0] if which == 0 else [0.2, 0.2, 0.2]      # final.cpp:1078 / :1115
+    e.start_nr = 2.40; e.max_depth = 6; e.ncaustic_sphere = 1
+    for k, v in enumerate((0.2, -0.3, 0.45, 0.2)):                         # causticSphere, final.cpp:754-758
+        e.caustic_sphere[0][k] = v
+    e.caustic_floor_y = -0.3; e.seed = seed
+    return e
+
+
+def gen_final():
+    """Photon-mapping renderer: outputs of the reference's own PhotonTrace / PhotonTraceCaustics / AddPhoton /
+    balance / TraceIrradiance / IsInShadow / GetSamplePoses / TestVisualizeLight / SimpleMeshRayTrace(pmap, cpmap)
+    on the bundled Final scene, through oracle/ref_harness_final.cpp.  Random draws are the reference's own engine
+    with the seed pinned by oracle/ref_time_shim.h (final.cpp's and photon.cpp's copies of mRandom both start there)."""
+    sd = scene.parse_scene_file(os.path.join(G, "final_input.txt"), flavour="final")
+    R = ol.ref_final_build_scene(sd)
+    cs = np.array([0.2, -0.3, 0.45, 0.2], f32); R.reff_add_caustic_sphere(cs.ctypes.data)
+    rng = np.random.default_rng(3)
+    out = dict(seed=R.reff_seed())
+    # light sampling + light quads
+    smp = np.zeros((400, 3), f32); out["nsamples"] = R.reff_light_samples(0, smp.ctypes.data, 400); out["light_samples"] = smp
+    q = np.zeros((2, 9), f32); R.reff_light_quads(q.ctypes.data); out["light_quads"] = q
+    # emission: caller-given rays, the reference's russian roulette
+    R.reff_maps_create(30000, 6000)
+    for which, n in ((0, 30500), (1, 9000)):
+        pos = np.zeros((n, 3), f32); pos[:, 0] = 0.3 + rng.uniform(-0.1, 0.1, n); pos[:, 1] = 0.49; pos[:, 2] = 0.7 + rng.uniform(-0.1, 0.1, n)
+        if which == 0:
+            d = rng.normal(size=(n, 3)); d[:, 1] = -np.abs(d[:, 1])
+        else:
+            d = cs[:3] + rng.normal(scale=0.1, size=(n, 3)) - pos
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+        col = np.array([3.0, 3.0, 3.0] if which == 0 else [0.2, 0.2, 0.2], f32)
+        R.reff_photon_trace(which, pos.ctypes.data, d.ctypes.data, col.ctypes.data, 2.40, n)
+        ns = R.reff_map_stored(which)
+        st = np.zeros(ns + 1, abi.photon_dtype); R.reff_map_dump(which, st.ctypes.data); st[0] = np.zeros(1, abi.photon_dtype)[0]
+        out[f"emit{which}_pos"] = pos; out[f"emit{which}_dir"] = d; out[f"emit{which}_stored"] = st.view(np.uint8)
+        print("final: map", which, "emissions", n, "stored", ns)
+    R.reff_map_balance_scale(0); R.reff_map_balance_scale(1)
+    heaps = []
+    for which in (0, 1):
+        ns = R.reff_map_stored(which)
+        h = np.zeros(ns + 1, abi.photon_dtype); R.reff_map_dump(which, h.ctypes.data); h[0] = np.zeros(1, abi.photon_dtype)[0]
+        R.reff_map_load(which, h.ctypes.data, ns)
+        heaps.append(h); out[f"heap{which}"] = h.view(np.uint8)
+    # TraceIrradiance
+    n = 1500
+    ori = rng.uniform(-0.45, 0.45, (n, 3)).astype(f32); ori[:, 2] += 0.5
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+    out["ti_ori"] = ori; out["ti_dir"] = d
+    for depth in (1, 2, 3, 4):
+        rgb = np.zeros((n, 3), f32); R.reff_trace_irradiance(ori.ctypes.data, d.ctypes.data, depth, 2.4, n, rgb.ctypes.data)
+        out[f"ti_rgb_d{depth}"] = rgb
+    # IsInShadow
+    pts = rng.uniform(-0.45, 0.45, (n, 3)).astype(f32); pts[:, 2] += 0.5
+    nr = rng.normal(size=(n, 3)); nr = (nr / np.linalg.norm(nr, axis=1, keepdims=True)).astype(f32)
+    lp = np.zeros((n, 3), f32); lp[:, 0] = 0.3 + rng.uniform(-.1, .1, n); lp[:, 1] = 0.49; lp[:, 2] = 0.7 + rng.uniform(-.1, .1, n)
+    sh = np.zeros(n, np.uint8); R.reff_is_in_shadow(pts.ctypes.data, lp.ctypes.data, nr.ctypes.data, n, sh.ctypes.data)
+    out.update(sh_point=pts, sh_normal=nr, sh_light=lp, sh_result=sh)
+    # the eye path: 16x16 primary rays of the native camera, the reference's serial engine from its seed
+    cam = ol.oracle_camera(sd.eye, sd.view, sd.fov, 16, 16)
+    xs, ys = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    rays = ol.oracle_primary_rays(cam, xs.ravel(), ys.ravel())
+    o3 = np.ascontiguousarray(rays[:, :3]); d3 = np.ascontiguousarray(rays[:, 3:])
+    rgb = np.zeros((256, 3), f32); ha = np.zeros(256, np.uint8)
+    R.reff_eye_trace(o3.ctypes.data, d3.ctypes.data, 0, 2.4, 256, rgb.ctypes.data, ha.ctypes.data)
+    sl = np.zeros(256, np.uint8); R.reff_sees_light(o3.ctypes.data, d3.ctypes.data, 256, sl.ctypes.data)
+    out.update(eye_rays=rays, eye_rgb=rgb, eye_hit_any=ha, eye_sees_light=sl, eye_cam=ol.camera_to_array(cam))
+    np.savez_compressed(os.path.join(G, "final_golden.npz"), **out)
+    print("final golden: eye pixels hit", int(ha.sum()), "see light", int(sl.sum()), "shadowed", int(sh.sum()))
+
+
+def gen_quantise():
+    """AddPhoton's direction bytes (photon.cpp:846,869-882) for 60 000 random directions."""
+    R = ol.ref_photon()
+    n = 60000
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(n, 3)).astype(f32)
+    d[:64] = np.eye(3, dtype=f32)[rng.integers(0, 3, 64)] * rng.choice([-1, 1], (64, 1)).astype(f32)   # axis-aligned
+    z = np.zeros((n, 3), f32)
+    R.refp_create(n); R.refp_add(z.ctypes.data, d.ctypes.data, z.ctypes.data, n)
+    st = np.zeros(n + 1, abi.photon_dtype); R.refp_dump(st.ctypes.data)
+    np.savez_compressed(os.path.join(G, "photon_quantise.npz"), dir=d, phi=st["phi"][1:], theta=st["theta"][1:])
+    print("quantise golden:", n)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--only", default="", help="comma list: monkey,units,photon,final,quantise")
     a = ap.parse_args()
     if not ol.have_ref():
         sys.exit("oracle/_ref is missing: run `make -C oracle ref` in the build container")
     text = open(os.path.join(G, "monkey.txt")).read()
     sd = scene.parse_scene_text(text)
-    gen_monkey(sd, text, a.big)
-    gen_units()
-    gen_photon()
+    only = set(a.only.split(",")) if a.only else None
+    if not only or "monkey" in only: gen_monkey(sd, text, a.big)
+    if not only or "units" in only: gen_units()
+    if not only or "photon" in only: gen_photon()
+    if not only or "final" in only: gen_final()
+    if not only or "quantise" in only: gen_quantise()

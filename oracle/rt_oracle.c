@@ -598,8 +598,9 @@ void orc_direction_tables(float* cost, float* sint, float* cosp, float* sinp) {
 void orc_photon_quantize_dir(const float dir[3], uint8_t* phi_out, uint8_t* theta_out, float ndir[3]) {
     v3 d = vnorm(vload(dir));
     vstore(ndir, d);
-    int phi = (int)(atan2((double)d.y, (double)d.x) * (256.0 / (2.0 * M_PI)));
-    int theta = (int)(acos((double)d.z) * (256.0 / PM_PI));
+    /* inDir[i] is float&: overload resolution picks std::atan2(float,float) / std::acos(float) */
+    int phi = (int)(atan2f(d.y, d.x) * (256.0 / (2.0 * M_PI)));
+    int theta = (int)(acosf(d.z) * (256.0 / PM_PI));
     if (phi > 255) phi = 255;
     if (phi < 0) phi = (unsigned char)(phi + 256);
     *phi_out = (unsigned char)phi;
@@ -783,4 +784,406 @@ void orc_pmap_irradiance(const rt_photon* heap, int64_t n, const float* pos3, co
         rgb[3 * i] = ir[0]; rgb[3 * i + 1] = ir[1]; rgb[3 * i + 2] = ir[2];
     }
     free(idx); free(d2);
+}
+
+
+/* ======================================================================== */
+/* Photon-mapping renderer, Final/photon/final.cpp + photon.cpp               */
+
+/* ---- counter-based RNG (BUILD-DEFINED: the reference draws from one serial
+ * std::default_random_engine seeded by time(), photon.h:16-18, which no
+ * parallel program can replay; "parity unpinned" for the sample values, the
+ * consumers below follow the reference line by line).  24 random bits -> [0,1)
+ * exactly as generate_canonical<float,24> would deliver them. ---------------- */
+static inline uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+float orc_rng(uint64_t seed, uint64_t a, uint64_t b, uint64_t c) {
+    uint64_t x = mix64(seed + 0x9E3779B97F4A7C15ull * (a + 1));
+    x = mix64(x ^ (b * 0xC2B2AE3D27D4EB4Full));
+    x = mix64(x ^ (c * 0x165667B19E3779F9ull));
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+float orc_minstd_next(uint32_t* state);
+
+typedef struct { const rt_photon* heap; int64_t n; } pmap_t;
+
+typedef struct {
+    orc_scene* s; const rt_camera* cam; const rt_params* p;
+    pmap_t g, c;
+    int hit_any; int32_t first_prim;
+    uint64_t pixel_tap;            /* RNG key a: pixel index * 8 + tap */
+    float light_tris[8][2][9];     /* lightMeshes, final.cpp:710-731 */
+    int nlight_tris;
+    uint32_t* lcg;                 /* != NULL: gather draws come from the reference's serial engine (pinning only) */
+} pctx;
+
+static v3 calc_irradiance(orc_scene* s, const pmap_t* m, v3 pos, v3 normal, float maxDist, int k) {
+    float q[3], nr[3], rgb[3];
+    vstore(q, pos); vstore(nr, normal);
+    s->c.knn_lookups++;
+    if (!m->heap || m->n < 1) { return V(0, 0, 0); }   /* empty map: LocatePhoton finds nothing, found < 8 */
+    orc_pmap_irradiance(m->heap, m->n, q, nr, 1, k, maxDist, rgb);
+    return vload(rgb);
+}
+
+/* RectLight::GetSamplePoses, photon.h:90-111 (PointLight: :121-125) */
+int orc_light_samples(const rt_light* l, float* out3, int cap) {
+    if (l->type != RT_LIGHT_RECT) { if (cap >= 1) vstore(out3, vload(l->pos)); return 1; }
+    v3 dir1 = vnorm(vload(l->dir1)), dir2 = vnorm(vload(l->dir2)), pos = vload(l->pos);
+    v3 startPos = vsub(vsub(pos, vdivs(vmuls(dir1, l->size1), 2.0f)), vdivs(vmuls(dir2, l->size2), 2.0f));
+    int n = 0;
+    for (int i = 0; i < l->n1; i++) {
+        v3 nowPos = vadd(startPos, vdivs(vmuls(vmuls(dir1, l->size1), (float)i), (float)l->n1));
+        for (int j = 0; j < l->n2; j++) {
+            v3 t = vadd(nowPos, vdivs(vmuls(vmuls(dir2, l->size2), (float)j), (float)l->n2));
+            if (n < cap) vstore(out3 + 3 * n, t);
+            n++;
+        }
+    }
+    return n;
+}
+
+/* the two light triangles the RectL parser builds, final.cpp:710-731 */
+void orc_light_quad(const rt_light* l, float tris[2][9]) {
+    v3 pos = vload(l->pos), d1 = vload(l->dir1), d2 = vload(l->dir2);
+    v3 a = vmuls(vmuls(d1, l->size1), 0.5f), b = vmuls(vmuls(d2, l->size2), 0.5f);
+    vstore(tris[0] + 0, vsub(vsub(pos, a), b)); vstore(tris[0] + 3, vsub(vadd(pos, a), b)); vstore(tris[0] + 6, vadd(vsub(pos, a), b));
+    vstore(tris[1] + 0, vadd(vadd(pos, a), b)); vstore(tris[1] + 3, vsub(vadd(pos, a), b)); vstore(tris[1] + 6, vadd(vsub(pos, a), b));
+}
+
+/* refraction block shared by final.cpp:871-886, photon.cpp:521-534, :796-807.
+ * Returns cos2t; tdir / Re / Tr are NaN-laden when cos2t < 0 exactly as in the reference. */
+static float refract_terms(v3 dir, v3 normal, v3 normalL, float currentNr, v3* reflRay, v3* tdir, float* Re, float* Tr, int* into_out) {
+    *reflRay = vsub(dir, vmuls(dir, vdot(vmuls(normal, 2), normal)));      /* dir - normal*2*normal*dir: ((n*2)*n) is a dot */
+    int into = vdot(normal, normalL) > 0;
+    float nc = 1, nt = currentNr, nnt = into ? nc / nt : nt / nc, ddn = vdot(dir, normalL);
+    float cos2t = 1 - nnt * nnt * (1 - ddn * ddn);
+    v3 t = vsub(vmuls(dir, nnt), vmuls(normal, (into ? 1 : -1) * (ddn * nnt + sqrtf(cos2t))));
+    t = vnorm(t);
+    float a = nt - nc, b = nt + nc, R0 = a * a / (b * b), c = 1 - (into ? -ddn : vdot(t, normal));
+    *Re = R0 + (1 - R0) * c * c * c * c * c; *Tr = 1 - *Re;
+    *tdir = t; if (into_out) *into_out = into;
+    return cos2t;
+}
+
+/* TraceIrradiance, photon.cpp:714-820 */
+static v3 trace_irradiance(pctx* c, v3 ori, v3 dir, int depth, float currentNr) {
+    orc_scene* s = c->s;
+    if (depth > c->p->irradiance_max_depth) return V(0, 0, 0);
+    v3 colour = V(0, 0, 0), hitPoint; float nearestDis;
+    s->c.rays_gather++;
+    int32_t prim = closest(s, ori, dir, &nearestDis, &hitPoint);
+    if (prim < 0) return colour;
+    const rt_material* m = &s->mats[s->mat[prim]];
+    v3 normal = get_normal(s, prim, hitPoint), normalL = normal;
+    if (vdot(normal, dir) > 0) normalL = vmuls(normal, -1.0f);
+    if (m->Kd > 0) {
+        v3 col = calc_irradiance(s, &c->g, hitPoint, normal, c->p->knn_radius_global, c->p->knn_k);
+        colour = vadd(colour, vmuls(col, m->Kd));
+    }
+    if (m->reflect > 0.01f) {
+        float dot = vdot(dir, normal);
+        v3 reflected = vsub(dir, vmuls(normal, 2 * dot));
+        v3 rc = trace_irradiance(c, hitPoint, reflected, depth + 1, currentNr);
+        colour = vadd(colour, vmuls(rc, m->reflect));
+    }
+    if (m->refract > 0.01f) {
+        v3 reflRay, tdir; float Re, Tr;
+        refract_terms(dir, normal, normalL, currentNr, &reflRay, &tdir, &Re, &Tr, NULL);
+        v3 a = vmuls(trace_irradiance(c, hitPoint, reflRay, depth + 1, currentNr), Re);
+        v3 b = vmuls(trace_irradiance(c, hitPoint, tdir, depth + 1, currentNr), Tr);
+        return vadd(V(0, 0, 0) /* emissionColor, Mesh.h:32 */, vmuls(vadd(a, b), m->refract));   /* discards `colour`, :808 */
+    }
+    return colour;
+}
+
+/* SimpleMeshRayTrace(pmap, cpmap, ...), final.cpp:785-983.  code = position of this call in the
+ * recursion tree (root 1; reflect 4c+1; refract's reflRay 4c+2; tdir 4c+3): RNG key b. */
+static v3 photon_trace_eye(pctx* c, v3 ori, v3 dir, int depth, float currentNr, uint64_t code) {
+    orc_scene* s = c->s;
+    if (depth > c->p->max_depth) return V(0, 0, 0);
+    v3 colour = V(0, 0, 0), hitPoint; float nearestDis;
+    int32_t prim = closest(s, ori, dir, &nearestDis, &hitPoint);
+    v3 diffuse = V(0, 0, 0), specular = V(0, 0, 0);
+    if (depth == 0) { c->first_prim = prim; s->c.rays_primary++; }
+    if (prim < 0) return colour;
+    if (depth == 0) c->hit_any = 1;
+    const rt_material* m = &s->mats[s->mat[prim]];
+    v3 surf = vload(m->surf);
+    v3 normal = get_normal(s, prim, hitPoint), normalL = normal;
+    if (vdot(normal, dir) > 0) normalL = vmuls(normal, -1.0f);
+    if (m->reflect > 0.0001f) {
+        float dot = vdot(dir, normalL);
+        v3 reflected = vsub(dir, vmuls(normalL, 2 * dot));
+        s->c.rays_reflect++;
+        v3 rc = photon_trace_eye(c, hitPoint, reflected, depth + 1, currentNr, 4 * code + 1);
+        colour = vadd(colour, vmuls(rc, m->reflect));
+    }
+    if ((double)m->refract > 0.0001) {
+        v3 reflRay, tdir; float Re, Tr;
+        float cos2t = refract_terms(dir, normal, normalL, currentNr, &reflRay, &tdir, &Re, &Tr, NULL);
+        if (cos2t < 0) {
+            s->c.rays_refract++;
+            v3 rc = photon_trace_eye(c, hitPoint, reflRay, depth + 1, currentNr, 4 * code + 2);
+            colour = vadd(colour, vmuls(rc, m->refract));
+        } else {
+            s->c.rays_refract += 2;
+            /* final.cpp:894-895 `f(reflRay)*Re + f(tdir)*Tr`: g++ evaluates the right operand first, which only
+             * matters for the order in which the serial engine is consumed (pinning mode) */
+            v3 b = vmuls(photon_trace_eye(c, hitPoint, tdir, depth + 1, currentNr, 4 * code + 3), Tr);
+            v3 a = vmuls(photon_trace_eye(c, hitPoint, reflRay, depth + 1, currentNr, 4 * code + 2), Re);
+            colour = vadd(colour, vmuls(vadd(a, b), m->refract));
+        }
+    }
+    /* caustics, final.cpp:909 */
+    colour = vadd(colour, calc_irradiance(s, &c->c, hitPoint, normal, c->p->knn_radius_caustic, c->p->knn_k));
+    /* global illumination, final.cpp:916-931 */
+    const int G = c->p->gather_samples;
+    for (int i = 0; i < G; i++) {
+        double r1 = 2.0 * PM_PI * (c->lcg ? orc_minstd_next(c->lcg) : orc_rng(c->p->seed, c->pixel_tap, code, 2 * (uint64_t)i));
+        double r2 = c->lcg ? orc_minstd_next(c->lcg) : orc_rng(c->p->seed, c->pixel_tap, code, 2 * (uint64_t)i + 1), r2s = sqrt(r2);
+        v3 w = normalL;
+        v3 u = vnorm(vcross(fabsf(w.x) > 0.1 ? V(0, 1.0f, 0) : V(1.0f, 0, 0), w));
+        v3 v = vcross(w, u);
+        v3 d = vadd(vadd(vmuls(vmuls(u, (float)cos(r1)), (float)r2s), vmuls(vmuls(v, (float)sin(r1)), (float)r2s)),
+                    vmuls(w, (float)sqrt(1 - r2)));
+        d = vnorm(d);
+        v3 temp = vdivs(trace_irradiance(c, hitPoint, d, depth + 1, currentNr), (float)G);
+        colour = vadd(colour, temp);
+    }
+    /* direct illumination, final.cpp:944-975 */
+    for (int i = 0; i < s->nlight; i++) {
+        static float samples[3 * 65536];
+        int ns = orc_light_samples(&s->lights[i], samples, 65536);
+        if (ns > 65536) ns = 65536;
+        float factor = (float)(1.0 / (ns >= 1 ? ns : 1));
+        for (int j = 0; j < ns; j++) {
+            v3 lpos = vload(samples + 3 * j);
+            /* IsInShadow, final.cpp:985-1018 */
+            v3 point = vadd(hitPoint, vmuls(normalL, s->shadow_bias));
+            v3 rayDir = vnorm(vsub(lpos, point));
+            float tLight = vlen(vsub(lpos, point));
+            s->c.rays_shadow++;
+            if (!any_hit(s, point, rayDir, 1, tLight)) {
+                v3 toLight = vnorm(vsub(lpos, hitPoint));
+                float dot = maxf_std(vdot(toLight, normalL), 0.0f);
+                v3 isurf = vmuls(surf, s->lights[i].intensity);
+                diffuse = vmuls(isurf, m->Kd * dot);
+                v3 eyeVec = vnorm(vsub(vload(c->cam->center), hitPoint));
+                v3 halfVec = vnorm(vadd(eyeVec, toLight));
+                dot = maxf_std(vdot(halfVec, normalL), 0.0f);
+                specular = vmuls(vmuls(isurf, m->Ks), powf(dot, m->specularity));
+            }
+            colour = vadd(colour, vmuls(vadd(diffuse, specular), factor));
+        }
+    }
+    return colour;
+}
+
+static const float AA_FILTER[6][3] = {      /* final.cpp:1033-1043 */
+    { -0.52f, 0.38f, 0.128f }, { 0.41f, 0.56f, 0.119f }, { 0.27f, 0.08f, 0.294f },
+    { -0.17f, -0.29f, 0.249f }, { 0.58f, -0.55f, 0.104f }, { -0.31f, -0.71f, 0.106f } };
+
+/* pixel loop of PhotonMappingImageSynthesis, final.cpp:1146-1202.  aa_taps == 0: one centre sample
+ * of weight 1 (build-defined convenience); 1..6: the first taps of AAFilter. */
+void orc_render_photon(orc_scene* s, const rt_camera* cam, const rt_params* p,
+                       const rt_photon* gheap, int64_t gn, const rt_photon* cheap, int64_t cn,
+                       uint8_t* rgb8, int32_t* hit_ids, float* radiance) {
+    pctx c; memset(&c, 0, sizeof c);
+    c.s = s; c.cam = cam; c.p = p; c.g.heap = gheap; c.g.n = gn; c.c.heap = cheap; c.c.n = cn;
+    for (int i = 0; i < s->nlight && c.nlight_tris < 8; i++)
+        if (s->lights[i].type == RT_LIGHT_RECT) orc_light_quad(&s->lights[i], c.light_tris[c.nlight_tris++]);
+    const int ntap = p->aa_taps > 0 ? (p->aa_taps > 6 ? 6 : p->aa_taps) : 1;
+    for (int x = 0; x < cam->resx; x++) {
+        for (int y = 0; y < cam->resy; y++) {
+            size_t px = (size_t)x + (size_t)y * (size_t)cam->resx;
+            v3 color = V(0, 0, 0);
+            c.hit_any = 0; c.first_prim = -1;
+            int32_t centre_prim = -1;
+            for (int aa = 0; aa < ntap; aa++) {
+                float vx = p->aa_taps > 0 ? x + AA_FILTER[aa][0] : (float)x;
+                float vy = p->aa_taps > 0 ? y + AA_FILTER[aa][1] : (float)y;
+                float wgt = p->aa_taps > 0 ? AA_FILTER[aa][2] : 1.0f;
+                rt_ray r; orc_primary_ray(cam, vx, vy, &r);
+                int sees_light = 0;                                   /* TestVisualizeLight, final.cpp:1021-1031 */
+                for (int l = 0; l < c.nlight_tris && !sees_light; l++)
+                    for (int t = 0; t < 2; t++) { float pt[3]; if (orc_tri_test(c.light_tris[l][t], r.o, r.d, pt)) { sees_light = 1; break; } }
+                if (sees_light) { color = V(1.0f, 1.0f, 1.0f); c.hit_any = 1; break; }
+                c.pixel_tap = (uint64_t)px * 8 + (uint64_t)aa;
+                v3 col = photon_trace_eye(&c, vload(r.o), vload(r.d), 0, p->start_nr, 1);
+                if (aa == 0) centre_prim = c.first_prim;
+                color = vadd(color, vmuls(col, wgt));
+            }
+            if (c.hit_any) {
+                rgb8[3 * px + 0] = quant(color.x); rgb8[3 * px + 1] = quant(color.y); rgb8[3 * px + 2] = quant(color.z);
+            } else {
+                rgb8[3 * px + 0] = (uint8_t)p->background[0]; rgb8[3 * px + 1] = (uint8_t)p->background[1];
+                rgb8[3 * px + 2] = (uint8_t)p->background[2];
+            }
+            if (hit_ids) hit_ids[px] = centre_prim;      /* hit id of the first tap's primary ray */
+            if (radiance) { radiance[3 * px] = color.x; radiance[3 * px + 1] = color.y; radiance[3 * px + 2] = color.z; }
+        }
+    }
+}
+
+/* ---- photon emission: final.cpp:1057-1119, photon.cpp:445-710, :835-885 ---- */
+typedef struct {
+    orc_scene* s; const rt_emit_params* e; uint64_t key_a; uint64_t draw;
+    rt_photon* out; int64_t cap, n;
+    uint32_t* lcg;                 /* != NULL: draw from the reference's serial engine instead (pinning only) */
+} ectx;
+
+/* std::default_random_engine (= minstd_rand0) + uniform_real_distribution<float>(0,1) as libstdc++
+ * evaluates them (photon.h:16-18): x <- 16807 x mod (2^31-1); generate_canonical<float,24> takes one
+ * draw: float(x - 1) / float(2147483646.0L) = float(x-1) / 2147483648.0f, clamped below 1. */
+float orc_minstd_next(uint32_t* state) {
+    *state = (uint32_t)(((uint64_t)*state * 16807ull) % 2147483647ull);
+    float r = (float)(*state - 1u) / 2147483648.0f;
+    if (r >= 1.0f) r = nextafterf(1.0f, 0.0f);
+    return r;
+}
+uint32_t orc_minstd_seed(uint32_t seed) { uint32_t x = seed % 2147483647u; return x == 0 ? 1u : x; }
+
+static float edraw(ectx* c) {
+    if (c->lcg) return orc_minstd_next(c->lcg);
+    return orc_rng(c->e->seed, c->key_a, c->draw++, 0);
+}
+
+/* AddPhoton, photon.cpp:835-885 (the map-full test :837 is the caller's truncation) */
+static void add_photon(ectx* c, v3 pos, v3 inDir, v3 power) {
+    if (c->n < c->cap) {
+        rt_photon* p = &c->out[c->n];
+        float d[3], nd[3]; vstore(d, inDir);
+        orc_photon_quantize_dir(d, &p->phi, &p->theta, nd);
+        vstore(p->position, pos); vstore(p->power, power); vstore(p->inDir, vload(nd));
+        p->plane = 0;
+    }
+    c->n++;
+}
+
+/* PhotonTrace, photon.cpp:445-568 */
+static void photon_trace(ectx* c, v3 ori, v3 dir, int depth, float currentNr, v3 lightColor) {
+    orc_scene* s = c->s;
+    if (depth >= c->e->max_depth) return;
+    float nearestDis; v3 hitPoint;
+    int32_t prim = closest(s, ori, dir, &nearestDis, &hitPoint);
+    if (prim < 0) return;
+    const rt_material* m = &s->mats[s->mat[prim]];
+    v3 normal = get_normal(s, prim, hitPoint), normalL = normal;
+    if (vdot(normal, dir) > 0) normalL = vmuls(normalL, -1.0f);
+    float REFLECT_PROB = m->reflect, REFRACT_PROB = m->refract;
+    float ABSORP_PROB = (float)(1.0 - REFLECT_PROB - REFRACT_PROB > 0 ? 1.0 - REFLECT_PROB - REFRACT_PROB : 0);
+    float rr = edraw(c);
+    if (rr < REFLECT_PROB) {
+        float dot = vdot(dir, normal);
+        v3 reflected = vsub(dir, vmuls(normal, 2 * dot));
+        (void)edraw(c);                                   /* russianRoulette = mRandom()*(wd+ws): drawn, unused (:513) */
+        photon_trace(c, hitPoint, reflected, depth + 1, currentNr, lightColor);
+    } else if (rr < REFLECT_PROB + REFRACT_PROB) {
+        v3 reflRay, tdir; float Re, Tr;
+        float cos2t = refract_terms(dir, normal, normalL, currentNr, &reflRay, &tdir, &Re, &Tr, NULL);
+        if (cos2t < 0) photon_trace(c, hitPoint, reflRay, depth + 1, currentNr, lightColor);   /* no return: falls through, :524-530 */
+        float P = (float)(.25 + .5 * Re), RP = Re / P, TP = Tr / (1 - P);
+        if (rr > REFLECT_PROB) photon_trace(c, hitPoint, reflRay, depth + 1, currentNr, vmuls(lightColor, RP));
+        else photon_trace(c, hitPoint, tdir, depth + 1, currentNr, vmuls(lightColor, TP));
+    } else {
+        v3 sc = vload(m->surf);
+        v3 power = V(sc.x * lightColor.x / ABSORP_PROB, sc.y * lightColor.y / ABSORP_PROB, sc.z * lightColor.z / ABSORP_PROB);
+        add_photon(c, hitPoint, dir, power);
+    }
+}
+
+/* PhotonTraceCaustics, photon.cpp:570-710 */
+static void photon_trace_caustics(ectx* c, v3 ori, v3 dir, int depth, float currentNr, v3 lightColor, int flag) {
+    orc_scene* s = c->s;
+    if (dir.y > 0) return;
+    if (!flag) {
+        int bb = 0; float o[3], d[3], pt[3]; vstore(o, ori); vstore(d, dir);
+        for (int i = 0; i < c->e->ncaustic_sphere; i++)
+            if (orc_sphere_test(c->e->caustic_sphere[i], c->e->caustic_sphere[i][3], o, d, pt)) { bb = 1; break; }
+        if (!bb) return;
+    }
+    if (depth >= 2) return;
+    float nearestDis; v3 hitPoint;
+    int32_t prim = closest(s, ori, dir, &nearestDis, &hitPoint);
+    if (prim < 0) return;
+    const rt_material* m = &s->mats[s->mat[prim]];
+    if (!flag && m->refract < 0.01) return;
+    flag = 1;
+    v3 normal = get_normal(s, prim, hitPoint), normalL = normal;
+    if (vdot(normal, dir) > 0) normalL = vmuls(normalL, -1.0f);
+    float REFRACT_PROB = m->refract;
+    float rr = edraw(c);
+    if (rr < REFRACT_PROB) {
+        v3 reflRay, tdir; float Re, Tr;
+        refract_terms(dir, normal, normalL, currentNr, &reflRay, &tdir, &Re, &Tr, NULL);
+        photon_trace_caustics(c, hitPoint, tdir, depth + 1, currentNr, lightColor, flag);
+    } else {
+        v3 sc = vload(m->surf);
+        v3 power = V(sc.x * lightColor.x, sc.y * lightColor.y, sc.z * lightColor.z);
+        if (hitPoint.y > c->e->caustic_floor_y) return;
+        add_photon(c, hitPoint, dir, power);
+    }
+}
+
+/* one pass of the `while` bodies at final.cpp:1057-1086 / :1090-1119 per emission index;
+ * photons come out in emission order.  Returns the number stored (may exceed cap: then only
+ * the first cap were written). */
+int64_t orc_emit_photons(orc_scene* s, const rt_emit_params* e, int64_t first, int64_t count,
+                         rt_photon* out, int64_t cap) {
+    ectx c; c.s = s; c.e = e; c.out = out; c.cap = cap; c.n = 0; c.lcg = NULL;
+    const rt_light* l = &s->lights[e->light];
+    for (int64_t k = first; k < first + count; k++) {
+        c.key_a = ((uint64_t)e->which << 60) | (uint64_t)k; c.draw = 0;
+        float offset_x = edraw(&c), offset_y = edraw(&c);
+        v3 d1 = vmuls(vload(l->dir1), l->size1), d2 = vmuls(vload(l->dir2), l->size2);
+        v3 pos = vadd(vsub(vadd(vsub(vload(l->pos), vmuls(d1, 0.5f)), vmuls(d1, offset_x)), vmuls(d2, 0.5f)), vmuls(d2, offset_y));
+        v3 nl = V(0, -1.0f, 0);
+        float r1 = (float)(2 * PM_PI * edraw(&c)), r2 = edraw(&c), r2s = sqrtf(r2);
+        v3 w = nl, u = vnorm(vcross(V(1.0f, 0, 0), w)), v = vcross(w, u);
+        v3 d = vadd(vadd(vmuls(vmuls(u, cosf(r1)), r2s), vmuls(vmuls(v, sinf(r1)), r2s)), vmuls(w, sqrtf(1 - r2)));
+        d = vnorm(d);
+        v3 color = vload(e->power);
+        if (e->which == RT_PMAP_GLOBAL) photon_trace(&c, pos, d, 0, e->start_nr, color);
+        else photon_trace_caustics(&c, pos, d, 0, e->start_nr, color, 0);
+    }
+    return c.n;
+}
+
+
+/* ---- entry points used only to pin the restatement against the reference harness ---------- */
+
+/* PhotonTrace / PhotonTraceCaustics for caller-given emission rays, russian-roulette draws taken
+ * from the reference's serial engine (*lcg_state carries on across calls as photon.cpp's copy does) */
+int64_t orc_photon_trace_serial(orc_scene* s, const rt_emit_params* e, const float* pos3, const float* dir3,
+                                int64_t n, uint32_t* lcg_state, rt_photon* out, int64_t cap) {
+    ectx c; c.s = s; c.e = e; c.out = out; c.cap = cap; c.n = 0; c.lcg = lcg_state; c.key_a = 0; c.draw = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (e->which == RT_PMAP_GLOBAL) photon_trace(&c, vload(pos3 + 3 * i), vload(dir3 + 3 * i), 0, e->start_nr, vload(e->power));
+        else photon_trace_caustics(&c, vload(pos3 + 3 * i), vload(dir3 + 3 * i), 0, e->start_nr, vload(e->power), 0);
+    }
+    return c.n;
+}
+
+void orc_trace_irradiance(orc_scene* s, const rt_params* p, const rt_photon* gheap, int64_t gn,
+                          const float* ori3, const float* dir3, int depth, float nr, int64_t n, float* rgb) {
+    pctx c; memset(&c, 0, sizeof c);
+    c.s = s; c.p = p; c.g.heap = gheap; c.g.n = gn;
+    for (int64_t i = 0; i < n; i++) vstore(rgb + 3 * i, trace_irradiance(&c, vload(ori3 + 3 * i), vload(dir3 + 3 * i), depth, nr));
+}
+
+void orc_eye_trace(orc_scene* s, const rt_camera* cam, const rt_params* p, const rt_photon* gheap, int64_t gn,
+                   const rt_photon* cheap, int64_t cn, const float* ori3, const float* dir3, int depth, float nr,
+                   int64_t n, uint32_t* lcg_state, float* rgb, uint8_t* hit_any) {
+    pctx c; memset(&c, 0, sizeof c);
+    c.s = s; c.cam = cam; c.p = p; c.g.heap = gheap; c.g.n = gn; c.c.heap = cheap; c.c.n = cn; c.lcg = lcg_state;
+    for (int64_t i = 0; i < n; i++) {
+        c.hit_any = 0; c.pixel_tap = (uint64_t)i * 8;
+        /* depth is passed through; hit_any is set only when depth == 0, final.cpp:829 */
+        vstore(rgb + 3 * i, photon_trace_eye(&c, vload(ori3 + 3 * i), vload(dir3 + 3 * i), depth, nr, 1));
+        hit_any[i] = (uint8_t)c.hit_any;
+    }
 }

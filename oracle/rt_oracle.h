@@ -35,6 +35,7 @@ typedef struct orc_counters {
     double  average_check;  /* `averageCheck`, hw4.cpp:1106                  */
     int64_t node_pops;      /* nodes popped (each is box-tested a second time, hw4.cpp:825) */
     int64_t rays_traced;    /* closest + any traversals                      */
+    int64_t rays_gather;    /* TraceIrradiance calls that traced (photon.cpp:714) */
 } orc_counters;
 
 /* flattened view of the KD trees, for comparing builders */
@@ -92,6 +93,25 @@ void orc_pmap_knn(const rt_photon* heap, int64_t n, const float* pos3, int64_t q
                   int32_t* idx, float* dist2, int32_t* found, float* radius2, int64_t* visits);
 void orc_pmap_irradiance(const rt_photon* heap, int64_t n, const float* pos3, const float* nrm3,
                          int64_t q, int k, float maxDist, float* rgb);
+
+/* photon-mapping renderer (final.cpp:785-1209, photon.cpp:714-820) with the build's counter RNG */
+float orc_rng(uint64_t seed, uint64_t a, uint64_t b, uint64_t c);
+int  orc_light_samples(const rt_light* l, float* out3, int cap);
+void orc_light_quad(const rt_light* l, float tris[2][9]);
+void orc_render_photon(orc_scene* s, const rt_camera* cam, const rt_params* p,
+                       const rt_photon* gheap, int64_t gn, const rt_photon* cheap, int64_t cn,
+                       uint8_t* rgb8, int32_t* hit_ids, float* radiance);
+float orc_minstd_next(uint32_t* state);
+uint32_t orc_minstd_seed(uint32_t seed);
+int64_t orc_photon_trace_serial(orc_scene* s, const rt_emit_params* e, const float* pos3, const float* dir3,
+                                int64_t n, uint32_t* lcg_state, rt_photon* out, int64_t cap);
+void orc_trace_irradiance(orc_scene* s, const rt_params* p, const rt_photon* gheap, int64_t gn,
+                          const float* ori3, const float* dir3, int depth, float nr, int64_t n, float* rgb);
+void orc_eye_trace(orc_scene* s, const rt_camera* cam, const rt_params* p, const rt_photon* gheap, int64_t gn,
+                   const rt_photon* cheap, int64_t cn, const float* ori3, const float* dir3, int depth, float nr,
+                   int64_t n, uint32_t* lcg_state /* NULL: counter RNG */, float* rgb, uint8_t* hit_any);
+int64_t orc_emit_photons(orc_scene* s, const rt_emit_params* e, int64_t first, int64_t count,
+                         rt_photon* out, int64_t cap);
 
 #ifdef __cplusplus
 }

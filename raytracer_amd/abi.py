@@ -57,6 +57,12 @@ class rt_params(C.Structure):
                 ("count_work", _i32), ("seed", C.c_uint64)]
 
 
+class rt_emit_params(C.Structure):
+    _fields_ = [("which", _i32), ("light", _i32), ("power", _f * 3), ("start_nr", _f), ("max_depth", _i32),
+                ("ncaustic_sphere", _i32), ("caustic_sphere", (_f * 4) * 4), ("caustic_floor_y", _f),
+                ("seed", C.c_uint64)]
+
+
 class rt_stats(C.Structure):
     _fields_ = [("rays_primary", _i64), ("rays_shadow", _i64), ("rays_reflect", _i64), ("rays_refract", _i64),
                 ("rays_gather", _i64), ("knn_lookups", _i64), ("passes", _i64), ("kernel_ms", C.c_double),
@@ -132,8 +138,8 @@ def load():
         L.rt_render_dev.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, vp, C.POINTER(rt_stats), vp]
     if hasattr(L, "rt_photonmap_upload"):
         L.rt_photonmap_upload.argtypes = [vp, i32, vp, i64]
-        L.rt_photonmap_build.argtypes = [vp, i32, vp, i64]
-        L.rt_photonmap_emit.argtypes = [vp, i32, i64, i64, C.c_uint64, vp, i64, C.POINTER(i64)]
+        L.rt_photonmap_build.argtypes = [vp, i32, vp, i64, C.c_float]
+        L.rt_photonmap_emit.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64)]
         L.rt_photon_knn.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp]
         L.rt_photon_knn_dev.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]
         L.rt_photon_irradiance.argtypes = [vp, i32, vp, vp, i64, i32, C.c_float, vp]

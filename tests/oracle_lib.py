@@ -21,7 +21,7 @@ class orc_counters(C.Structure):
     _fields_ = [("rays_primary", i64), ("rays_shadow", i64), ("rays_reflect", i64), ("rays_refract", i64),
                 ("box_tests", i64), ("tri_tests", i64), ("leaf_refs_read", i64), ("knn_lookups", i64),
                 ("knn_node_visits", i64), ("knn_found", i64), ("average_check", C.c_double),
-                ("node_pops", i64), ("rays_traced", i64)]
+                ("node_pops", i64), ("rays_traced", i64), ("rays_gather", i64)]
 
 
 class orc_kd_flat(C.Structure):
@@ -62,6 +62,22 @@ def oracle():
         L.orc_pmap_balance.argtypes = [vp, i64]
         L.orc_pmap_knn.argtypes = [vp, i64, vp, i64, i32, f32, vp, vp, vp, vp, vp]
         L.orc_pmap_irradiance.argtypes = [vp, i64, vp, vp, i64, i32, f32, vp]
+        L.orc_rng.restype = f32
+        L.orc_rng.argtypes = [C.c_uint64] * 4
+        L.orc_light_samples.argtypes = [C.POINTER(abi.rt_light), vp, i32]
+        L.orc_light_quad.argtypes = [C.POINTER(abi.rt_light), vp]
+        L.orc_render_photon.argtypes = [vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), vp, i64, vp, i64, vp, vp, vp]
+        L.orc_emit_photons.restype = i64
+        L.orc_emit_photons.argtypes = [vp, C.POINTER(abi.rt_emit_params), i64, i64, vp, i64]
+        L.orc_minstd_next.restype = f32
+        L.orc_minstd_next.argtypes = [C.POINTER(C.c_uint32)]
+        L.orc_minstd_seed.restype = C.c_uint32
+        L.orc_minstd_seed.argtypes = [C.c_uint32]
+        L.orc_photon_trace_serial.restype = i64
+        L.orc_photon_trace_serial.argtypes = [vp, C.POINTER(abi.rt_emit_params), vp, vp, i64, C.POINTER(C.c_uint32), vp, i64]
+        L.orc_trace_irradiance.argtypes = [vp, C.POINTER(abi.rt_params), vp, i64, vp, vp, i32, f32, i64, vp]
+        L.orc_eye_trace.argtypes = [vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), vp, i64, vp, i64, vp, vp, i32,
+                                    f32, i64, C.POINTER(C.c_uint32), vp, vp]
         _O = L
     return _O
 
@@ -235,6 +251,55 @@ def ref_photon():
         L.refp_irradiance.argtypes = [vp, vp, i64, f32, i32, vp]
         _RP = L
     return _RP
+
+
+_RF = None
+
+
+def ref_final():
+    """the reference's photon-mapping renderer (final.cpp + photon.cpp) behind oracle/ref_harness_final.cpp"""
+    global _RF
+    if _RF is None:
+        L = C.CDLL(os.path.join(REF_DIR, "libref_final.so"))
+        L.reff_add_sphere.argtypes = [vp, vp]
+        L.reff_add_triangle.argtypes = [vp, vp]
+        L.reff_add_rectlight.argtypes = [vp, f32, f32, i32, i32]
+        L.reff_add_caustic_sphere.argtypes = [vp]
+        L.reff_camera_center.argtypes = [vp]
+        L.reff_light_quads.argtypes = [vp]
+        L.reff_light_samples.argtypes = [i32, vp, i32]
+        L.reff_is_in_shadow.argtypes = [vp, vp, vp, i64, vp]
+        L.reff_sees_light.argtypes = [vp, vp, i64, vp]
+        L.reff_maps_create.argtypes = [i32, i32]
+        L.reff_map_stored.argtypes = [i32]
+        L.reff_map_dump.argtypes = [i32, vp]
+        L.reff_map_load.argtypes = [i32, vp, i32]
+        L.reff_map_balance_scale.argtypes = [i32]
+        L.reff_random.argtypes = [i32, vp]
+        L.reff_photon_trace.argtypes = [i32, vp, vp, vp, f32, i64]
+        L.reff_trace_irradiance.argtypes = [vp, vp, i32, f32, i64, vp]
+        L.reff_eye_trace.argtypes = [vp, vp, i32, f32, i64, vp, vp]
+        _RF = L
+    return _RF
+
+
+def ref_final_build_scene(sd):
+    """Create the reference's globals from a flavour-"final" SceneData, as its parser would."""
+    L = ref_final()
+    L.reff_clear()
+    for i in range(sd.nprim):
+        mat = np.ascontiguousarray(sd.materials[sd.prim_material[i]], np.float32)
+        f = np.ascontiguousarray(sd.prims[i], np.float32)
+        if sd.prim_type[i] == abi.RT_PRIM_SPHERE:
+            L.reff_add_sphere(f.ctypes.data, mat.ctypes.data)
+        else:
+            L.reff_add_triangle(f.ctypes.data, mat.ctypes.data)
+    for l in sd.lights:
+        pos = np.ascontiguousarray(l["pos"], np.float32)
+        L.reff_add_rectlight(pos.ctypes.data, float(l["size1"]), float(l["size2"]), int(l["n1"]), int(l["n2"]))
+    e = np.ascontiguousarray(sd.eye, np.float32)
+    L.reff_camera_center(e.ctypes.data)
+    return L
 
 
 def ref_build_scene(sd, id_colour=False, with_lights=True):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from raytracer_amd import abi, host
+from raytracer_amd import abi, host, scene
 
 G = ol.GOLDEN
 
@@ -204,3 +204,117 @@ def test_live_reference_random_scene():
     h = o.trace_closest(rays)
     assert np.array_equal(h["prim"], prim) and (prim >= 0).sum() > 500
     o.close()
+
+
+# ---------------------------------------------------------------------------
+# photon-mapping renderer (final.cpp / photon.cpp) -- fixtures made by oracle/gen_golden.py:gen_final from
+# the reference's own functions with its own random engine (seed pinned at compile time)
+def _final_emit_params(which, seed=7):
+    e = abi.rt_emit_params(); e.which = which; e.light = 0
+    e.power[:] = [3.0, 3.0, 3.0] if which == 0 else [0.2, 0.2, 0.2]
+    e.start_nr = 2.40; e.max_depth = 6; e.ncaustic_sphere = 1
+    for k, v in enumerate((0.2, -0.3, 0.45, 0.2)):
+        e.caustic_sphere[0][k] = v
+    e.caustic_floor_y = -0.3; e.seed = seed
+    return e
+
+
+@pytest.fixture(scope="module")
+def final_osc():
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    o = ol.OracleScene(sd)
+    yield sd, o
+    o.close()
+
+
+def _eq_nan(a, b):
+    return bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def test_photon_quantisation_60k_directions():
+    """AddPhoton calls the FLOAT overloads atan2f / acosf (photon.cpp:869-870, inDir[i] is float&)."""
+    g = _load("photon_quantise.npz")
+    L = ol.oracle()
+    d = np.ascontiguousarray(g["dir"])
+    phi, th = C.c_uint8(), C.c_uint8(); nd = np.zeros(3, np.float32)
+    for i in range(d.shape[0]):
+        L.orc_photon_quantize_dir(d[i].ctypes.data, C.byref(phi), C.byref(th), nd.ctypes.data)
+        assert (phi.value, th.value) == (g["phi"][i], g["theta"][i]), i
+
+
+def test_final_serial_engine_and_light_sampling(final_osc):
+    sd, o = final_osc
+    g = _load("final_golden.npz")
+    L = ol.oracle()
+    la = sd.light_array()
+    s = np.zeros((400, 3), np.float32)
+    assert L.orc_light_samples(C.byref(la[0]), s.ctypes.data, 400) == g["nsamples"].item() == 400
+    assert np.array_equal(s, g["light_samples"])                       # RectLight::GetSamplePoses, photon.h:90-111
+    q = np.zeros((2, 9), np.float32); L.orc_light_quad(C.byref(la[0]), q.ctypes.data)
+    assert np.array_equal(q, g["light_quads"])                         # lightMeshes, final.cpp:710-731
+
+
+def test_final_photon_trace_vs_reference(final_osc):
+    """PhotonTrace / PhotonTraceCaustics / AddPhoton: every stored photon bit for bit (serial engine replayed)."""
+    sd, o = final_osc
+    g = _load("final_golden.npz")
+    L = ol.oracle()
+    st = C.c_uint32(L.orc_minstd_seed(int(g["seed"].item())))
+    for which, cap in ((0, 30000), (1, 6000)):
+        want = g[f"emit{which}_stored"].view(abi.photon_dtype)
+        pos = np.ascontiguousarray(g[f"emit{which}_pos"]); d = np.ascontiguousarray(g[f"emit{which}_dir"])
+        e = _final_emit_params(which)
+        out = np.zeros(cap, abi.photon_dtype)
+        # the reference's map was full at `cap` (AddPhoton drops the rest, photon.cpp:837) but kept drawing
+        n = L.orc_photon_trace_serial(o.h, C.byref(e), pos.ctypes.data, d.ctypes.data, pos.shape[0], C.byref(st),
+                                      out.ctypes.data, cap)
+        assert n >= cap == want.size - 1
+        for f in ("position", "inDir", "power", "phi", "theta"):
+            assert _eq_nan(out[f].astype(np.float64), want[f][1:].astype(np.float64)), (which, f)
+
+
+def test_final_trace_irradiance_and_shadow_vs_reference(final_osc):
+    sd, o = final_osc
+    g = _load("final_golden.npz")
+    L = ol.oracle()
+    heap = g["heap0"].view(abi.photon_dtype).copy()
+    p = host.default_params("final")
+    ori = np.ascontiguousarray(g["ti_ori"]); d = np.ascontiguousarray(g["ti_dir"])
+    for depth in (1, 2, 3, 4):
+        rgb = np.zeros((ori.shape[0], 3), np.float32)
+        L.orc_trace_irradiance(o.h, C.byref(p), heap.ctypes.data, heap.size - 1, ori.ctypes.data, d.ctypes.data, depth, 2.4,
+                               ori.shape[0], rgb.ctypes.data)
+        assert _eq_nan(rgb, g[f"ti_rgb_d{depth}"]), depth
+    assert not g["ti_rgb_d4"].any() and g["ti_rgb_d1"].any()
+    n = g["sh_point"].shape[0]
+    rays = np.zeros((n, 6), np.float32); tl = np.zeros(n, np.float32)
+    for i in range(n):
+        t = C.c_float()
+        L.orc_shadow_ray(g["sh_point"][i].ctypes.data, g["sh_light"][i].ctypes.data, g["sh_normal"][i].ctypes.data, 1e-4,
+                         rays[i].ctypes.data, C.byref(t)); tl[i] = t.value
+    assert np.array_equal(o.trace_any(rays, tl), g["sh_result"])        # IsInShadow, final.cpp:985-1018
+
+
+def test_final_eye_path_vs_reference(final_osc):
+    """SimpleMeshRayTrace(pmap, cpmap, ...) (final.cpp:785-983) for 256 primary rays: caustic kNN, 50 gather rays
+    each through TraceIrradiance, 400 shadow samples with the stale diffuse/specular quirk -- radiance bit for bit
+    when the gather draws come from the reference's serial engine."""
+    sd, o = final_osc
+    g = _load("final_golden.npz")
+    L = ol.oracle()
+    gh = g["heap0"].view(abi.photon_dtype).copy(); ch = g["heap1"].view(abi.photon_dtype).copy()
+    cam = ol.oracle_camera(sd.eye, sd.view, sd.fov, 16, 16)
+    assert np.array_equal(ol.camera_to_array(cam), g["eye_cam"])
+    rays = g["eye_rays"]; o3 = np.ascontiguousarray(rays[:, :3]); d3 = np.ascontiguousarray(rays[:, 3:])
+    p = host.default_params("final")
+    st = C.c_uint32(L.orc_minstd_seed(int(g["seed"].item())))
+    rgb = np.zeros((256, 3), np.float32); ha = np.zeros(256, np.uint8)
+    L.orc_eye_trace(o.h, C.byref(cam), C.byref(p), gh.ctypes.data, gh.size - 1, ch.ctypes.data, ch.size - 1, o3.ctypes.data,
+                    d3.ctypes.data, 0, 2.4, 256, C.byref(st), rgb.ctypes.data, ha.ctypes.data)
+    assert _eq_nan(rgb, g["eye_rgb"]) and np.array_equal(ha, g["eye_hit_any"])
+    # TestVisualizeLight, final.cpp:1021-1031
+    q = g["light_quads"]
+    sees = np.zeros(256, np.uint8); pt = np.zeros(3, np.float32)
+    for i in range(256):
+        sees[i] = any(L.orc_tri_test(np.ascontiguousarray(q[t]).ctypes.data, o3[i].ctypes.data, d3[i].ctypes.data, pt.ctypes.data) for t in range(2))
+    assert np.array_equal(sees, g["eye_sees_light"])
