@@ -361,6 +361,15 @@ hipError_t rtk_accumulate(const int32_t* pix, const float* contrib, int64_t n, f
 
 int64_t rtk_scan_blocks_needed(int64_t nflags) { return (nflags + SCAN_TILE - 1) / SCAN_TILE; }
 
+// byte flags -> per-2048-tile exclusive offsets in block_sums, total in *d_total
+hipError_t rtk_scan_flags(const uint8_t* flags, int64_t n, uint32_t* block_sums, uint32_t* d_total, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t nb = rtk_scan_blocks_needed(n);
+    hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, n, block_sums);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, nb, d_total);
+    return hipGetLastError();
+}
+
 hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
                                 const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,

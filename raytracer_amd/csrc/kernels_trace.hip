@@ -20,341 +20,7 @@
 // operations in the reference's order on the nodes the reference would visit.
 //
 // Compile with -ffp-contract=off and correctly rounded f32 divide / sqrt.
-#include <hip/hip_runtime.h>
-#include "rt_internal.h"
-
-#define RT_ALIVE 0x7fffffff
-#define RT_DEAD  (-1)
-
-namespace {
-
-struct Rayf { float ox, oy, oz, dx, dy, dz; };
-
-__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
-
-// KDNode::HitTest, hw4.cpp:281-328.  lo/hi are center -/+ extend/2.0f.
-__device__ __forceinline__ bool box_test(const DevNode& n, const Rayf& r) {
-    float tmin = (n.lo[0] - r.ox) / r.dx;
-    float tmax = (n.hi[0] - r.ox) / r.dx;
-    if (tmin > tmax) { float t = tmin; tmin = tmax; tmax = t; }
-    float tymin = (n.lo[1] - r.oy) / r.dy;
-    float tymax = (n.hi[1] - r.oy) / r.dy;
-    if (tymin > tymax) { float t = tymin; tymin = tymax; tymax = t; }
-    if ((tmin > tymax) || (tymin > tmax)) return false;
-    if (tymin > tmin) tmin = tymin;
-    if (tymax < tmax) tmax = tymax;
-    float tzmin = (n.lo[2] - r.oz) / r.dz;
-    float tzmax = (n.hi[2] - r.oz) / r.dz;
-    if (tzmin > tzmax) { float t = tzmin; tzmin = tzmax; tzmax = t; }
-    if ((tmin > tzmax) || (tzmin > tmax)) return false;
-    return true;
-}
-
-// Triangle::IntersectionTest, hw4.cpp:171-231.  a = {v0, edge1, edge2}.
-// eps_f = smallest float above the reference's double `epsilon` 1e-6, so
-// (det > -epsilon && det < epsilon) in double  <=>  |det| < eps_f in float.
-__device__ __forceinline__ bool tri_test(const float* __restrict__ a, const Rayf& r, float eps_f,
-                                         float& px, float& py, float& pz) {
-    const float v0x = a[0], v0y = a[1], v0z = a[2];
-    const float e1x = a[3], e1y = a[4], e1z = a[5];
-    const float e2x = a[6], e2y = a[7], e2z = a[8];
-    // pvec = rayDir ^ edge2
-    const float pvx = r.dy * e2z - r.dz * e2y;
-    const float pvy = r.dz * e2x - r.dx * e2z;
-    const float pvz = r.dx * e2y - r.dy * e2x;
-    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
-    if (__builtin_fabsf(det) < eps_f) return false;
-    const float detInv = 1.0f / det;
-    const float tx = r.ox - v0x, ty = r.oy - v0y, tz = r.oz - v0z;
-    const float u = (tx * pvx + ty * pvy + tz * pvz) * detInv;
-    if (u < 0 || u > 1.0f) return false;
-    // qvec = tvec ^ edge1
-    const float qx = ty * e1z - tz * e1y;
-    const float qy = tz * e1x - tx * e1z;
-    const float qz = tx * e1y - ty * e1x;
-    const float v = (r.dx * qx + r.dy * qy + r.dz * qz) * detInv;
-    if (v < 0 || u + v > 1.0f) return false;
-    const float t = (e2x * qx + e2y * qy + e2z * qz) * detInv;
-    if (t < 0) return false;
-    px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
-    return true;
-}
-
-// Sphere::IntersectionTest, hw4.cpp:73-116.  a = {center, radius}.
-__device__ __forceinline__ bool sphere_test(const float* __restrict__ a, const Rayf& r,
-                                            float& px, float& py, float& pz) {
-    const float hx = a[0] - r.ox, hy = a[1] - r.oy, hz = a[2] - r.oz;
-    const float mu = hx * r.dx + hy * r.dy + hz * r.dz;
-    const float delta = (mu * mu) - (hx * hx + hy * hy + hz * hz) + (a[3] * a[3]);
-    if (delta < 0) return false;
-    const float sq = sqrt_rn(delta);
-    const float t1 = mu + sq, t2 = mu - sq;
-    if (t1 <= 0 && t2 <= 0) return false;
-    float t;
-    if (t1 >= 0 && t2 < 0) t = t1;
-    else if (t1 < 0 && t2 >= 0) t = t2;
-    else t = t1 < t2 ? t1 : t2;
-    px = r.ox + t * r.dx; py = r.oy + t * r.dy; pz = r.oz + t * r.dz;
-    return true;
-}
-
-// len = (ori - v).length(), hw4.cpp:851
-__device__ __forceinline__ float dist_to(const Rayf& r, float px, float py, float pz) {
-    const float ax = r.ox - px, ay = r.oy - py, az = r.oz - pz;
-    return sqrt_rn(ax * ax + ay * ay + az * az);
-}
-
-// vec3::normalize, algebra3.cpp:280-282,301: d_inv = 1./length (double divide)
-__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
-    const float len = sqrt_rn(x * x + y * y + z * z);
-    const float di = (float)(1.0 / (double)len);
-    x *= di; y *= di; z *= di;
-}
-
-// culling term of hw4.cpp:853 / final.cpp:808: GetNormal(v) * dir < 0
-__device__ __forceinline__ bool facing(const DevSceneView& sc, int prim, bool sphere, const Rayf& r,
-                                       float px, float py, float pz) {
-    float nx, ny, nz;
-    if (sphere) {
-        const float* g = sc.prim_geom + 4 * (size_t)prim;
-        nx = px - g[0]; ny = py - g[1]; nz = pz - g[2];
-        normalize3(nx, ny, nz);
-    } else {
-        const float* n = sc.prim_normal + 3 * (size_t)prim;
-        nx = n[0]; ny = n[1]; nz = n[2];
-    }
-    return (nx * r.dx + ny * r.dy + nz * r.dz) < 0;
-}
-
-struct Closest { float len; int prim; float px, py, pz; int rank; };
-
-// per-lane work counters of the measurement-only kernel k_trace_work (bench.py's algorithmic bytes)
-struct Work { unsigned box, tri, exact, fetch; };
-
-
-// ---------------------------------------------------------------------------
-// STRICT traversal: the reference's visit order and nothing else (no culling).
-// One wave = 64 rays.  ANY: stop at the first accepted hit per lane.
-template <bool ANY, bool COUNT = false>
-__device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, bool valid,
-                                         float eps_f, float tmax, bool use_tmax,
-                                         Closest& best, bool& occluded, Work* w = nullptr) {
-    int fail = valid ? RT_ALIVE : RT_DEAD;
-    const int nn = sc.nnodes;
-    int i = 0;
-    while (i < nn) {
-        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
-        const DevNode nd = sc.nodes[i];                 // wave-uniform address
-        const int depth = nd.meta & 0xff;
-        if (fail >= depth) fail = RT_ALIVE;             // left the subtree this lane had failed in
-        bool hit = false;
-        if (COUNT) w->fetch += 1;
-        if (fail == RT_ALIVE) {
-            if (COUNT) w->box += 1;
-            hit = box_test(nd, r);
-            if (!hit) fail = depth;
-        }
-        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
-        if (nd.meta & 0x100) {
-            for (int k = 0; k < nd.leaf_count; ++k) {
-                const DevLeafTri* __restrict__ t = sc.leaf_tris + (nd.leaf_first + k);   // wave-uniform
-                if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
-                if (COUNT) w->fetch += 1;
-                if (hit) {
-                    float px, py, pz;
-                    if (COUNT) { w->tri += 1; w->exact += 1; }
-                    if (tri_test(t->v0, r, eps_f, px, py, pz)) {
-                        const float len = dist_to(r, px, py, pz);
-                        if (ANY) {
-                            if (len < (use_tmax ? tmax : 1e9f) && len >= sc.tol_f) { occluded = true; fail = RT_DEAD; hit = false; }
-                        } else {
-                            if (len < best.len && len >= sc.tol_f &&
-                                (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
-                                best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        i = i + 1;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// FAST traversal: same accepted hits, fewer tests.
-//  * the wave walks the layout ordered for its rays' octant (near child first);
-//  * a lane skips a subtree that lies wholly behind its origin, or wholly beyond its current best hit by
-//    more than the subtree's slack: no hit the reference accepts there can win or tie;
-//  * ties (equal len) are resolved by the reference's visit rank (= leaf record index), so the winner is
-//    the one the reference's fixed order would have met first;
-//  * box booleans come from reciprocal-multiply slabs when the decision is clear of rounding doubt, and
-//    from the reference's divisions otherwise; triangle candidates are screened with an approximate
-//    reciprocal and confirmed with the reference's exact sequence.
-struct RayAux {
-    float rx, ry, rz;      // RN(1/d) per axis
-    float dlen;            // |dir|
-    bool plain;            // all direction components finite and non-zero, |dir| in [0.5, 2]: fast paths allowed
-};
-
-__device__ __forceinline__ RayAux ray_aux(const Rayf& r) {
-    RayAux a;
-    a.rx = 1.0f / r.dx; a.ry = 1.0f / r.dy; a.rz = 1.0f / r.dz;
-    a.dlen = sqrt_rn(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
-    const float big = 1e18f, small = 1e-18f;
-    const float ax = __builtin_fabsf(r.dx), ay = __builtin_fabsf(r.dy), az = __builtin_fabsf(r.dz);
-    a.plain = (ax > small && ax < big) && (ay > small && ay < big) && (az > small && az < big) &&
-              (a.dlen > 0.5f && a.dlen < 2.0f) &&
-              (__builtin_fabsf(r.ox) < big) && (__builtin_fabsf(r.oy) < big) && (__builtin_fabsf(r.oz) < big);
-    return a;
-}
-
-// returns the reference's HitTest boolean; enter/exit are slab parameters good to ~1e-6 relative
-__device__ __forceinline__ bool box_fast(const DevNode& n, const Rayf& r, const RayAux& a, float& enter, float& exit) {
-    const float x0 = (n.lo[0] - r.ox) * a.rx, x1 = (n.hi[0] - r.ox) * a.rx;
-    const float y0 = (n.lo[1] - r.oy) * a.ry, y1 = (n.hi[1] - r.oy) * a.ry;
-    const float z0 = (n.lo[2] - r.oz) * a.rz, z1 = (n.hi[2] - r.oz) * a.rz;
-    enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-    exit  = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-    const float gap = exit - enter;
-    // each slab value is within 2^-22 relative of the reference's rounded quotient; 2^-19 leaves 8x room
-    const float doubt = 1.9073486e-6f * (__builtin_fabsf(enter) + __builtin_fabsf(exit)) + 1e-30f;
-    if (a.plain && __builtin_fabsf(gap) > doubt) return gap > 0.0f;
-    return box_test(n, r);
-}
-
-template <bool ANY, bool COUNT = false>
-__device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf& r, bool valid,
-                                              float eps_f, float tmax, bool use_tmax,
-                                              Closest& best, bool& occluded, Work* w = nullptr) {
-    int fail = valid ? RT_ALIVE : RT_DEAD;
-    const RayAux aux = ray_aux(r);
-    // the wave's layout: octant of its first valid ray (any choice is correct, this one is fastest)
-    const unsigned long long vm = __ballot(valid);
-    if (vm == 0ull) return;
-    const int oct_l = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
-    const int oct = __builtin_amdgcn_readlane(oct_l, __builtin_ctzll(vm));
-    const DevNode* __restrict__ nodes = sc.nodes_oct[oct];
-    const float far_limit = ANY ? (use_tmax ? tmax : 1e9f) : 0.f;
-    const int nn = sc.nnodes;
-    int i = 0;
-    while (i < nn) {
-        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
-        const DevNode nd = nodes[i];                    // wave-uniform address
-        const int depth = nd.meta & 0xff;
-        if (fail >= depth) fail = RT_ALIVE;
-        bool hit = false;
-        if (COUNT) w->fetch += 1;
-        if (fail == RT_ALIVE) {
-            float enter, exit;
-            if (COUNT) w->box += 1;
-            hit = box_fast(nd, r, aux, enter, exit);
-            if (hit && aux.plain) {
-                // lengths along the ray of the slab interval, shrunk/grown by the subtree's slack
-                const float el = enter * aux.dlen, xl = exit * aux.dlen;
-                const float slack = nd.margin * (__builtin_fabsf(el) + __builtin_fabsf(xl)) + 1e-6f;
-                const float limit = ANY ? far_limit : best.len;
-                if (xl + slack < 0.0f || el - slack > limit) hit = false;   // behind the origin / beyond the best hit
-            }
-            if (!hit) fail = depth;
-        }
-        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
-        if (nd.meta & 0x100) {
-            for (int k = 0; k < nd.leaf_count; ++k) {
-                const int rank = nd.leaf_first + k;
-                const DevLeafTri* __restrict__ t = sc.leaf_tris + rank;            // wave-uniform
-                if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
-                // --- screening with an approximate reciprocal (same dot products as the exact test) ---
-                const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
-                const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
-                const float pvx = r.dy * e2z - r.dz * e2y;
-                const float pvy = r.dz * e2x - r.dx * e2z;
-                const float pvz = r.dx * e2y - r.dy * e2x;
-                const float det = e1x * pvx + e1y * pvy + e1z * pvz;
-                if (COUNT) { w->fetch += 1; if (hit) w->tri += 1; }
-                bool cand = hit && !(__builtin_fabsf(det) < eps_f);
-                const float ri = __builtin_amdgcn_rcpf(det);
-                const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
-                const float du = tx * pvx + ty * pvy + tz * pvz;
-                const float ua = du * ri;
-                cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
-                if (__ballot(cand) == 0ull) continue;
-                const float qx = ty * e1z - tz * e1y;
-                const float qy = tz * e1x - tx * e1z;
-                const float qz = tx * e1y - ty * e1x;
-                const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
-                const float dt = e2x * qx + e2y * qy + e2z * qz;
-                const float va = dv * ri, ta = dt * ri;
-                cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
-                if (__ballot(cand) == 0ull) continue;
-                // --- the reference's exact sequence for the survivors (hw4.cpp:211-230) ---
-                if (cand) {
-                    if (COUNT) w->exact += 1;
-                    const float detInv = 1.0f / det;
-                    const float u = du * detInv;
-                    if (!(u < 0 || u > 1.0f)) {
-                        const float v = dv * detInv;
-                        if (!(v < 0 || u + v > 1.0f)) {
-                            const float tt = dt * detInv;
-                            if (!(tt < 0)) {
-                                const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
-                                const float len = dist_to(r, px, py, pz);
-                                if (ANY) {
-                                    if (len < far_limit && len >= sc.tol_f) { occluded = true; fail = RT_DEAD; hit = false; }
-                                } else {
-                                    if ((len < best.len || (len == best.len && rank < best.rank)) && len >= sc.tol_f &&
-                                        (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
-                                        best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
-                                        best.rank = rank;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        i = i + 1;
-    }
-}
-
-// primitives outside every tree, in index order (the whole scene for final.cpp)
-template <bool ANY, bool COUNT = false>
-__device__ __forceinline__ void loose_prims(const DevSceneView& sc, const Rayf& r, bool valid,
-                                            float eps_f, float tmax, bool use_tmax,
-                                            Closest& best, bool& occluded, Work* w = nullptr) {
-    bool live = valid && !(ANY && occluded);
-    for (int k = 0; k < sc.nloose; ++k) {
-        if (ANY) { if (__ballot(live) == 0ull) break; }
-        const DevLoose* __restrict__ l = sc.loose + k;                              // wave-uniform
-        const int flags = l->flags;
-        if (ANY && use_tmax && (flags & RT_PF_SKIP_SHADOW)) continue;
-        if (COUNT) w->fetch += 1;
-        if (!live) continue;
-        if (COUNT) { w->tri += 1; w->exact += 1; }
-        float px, py, pz;
-        const bool sph = (flags & RT_PF_SPHERE) != 0;
-        const bool b = sph ? sphere_test(l->a, r, px, py, pz) : tri_test(l->a, r, eps_f, px, py, pz);
-        if (!b) continue;
-        const float len = dist_to(r, px, py, pz);
-        if (ANY) {
-            if (len < (use_tmax ? tmax : 1e9f) && len >= sc.tol_f) { occluded = true; live = false; }
-        } else {
-            // loose primitives come after every tree in the reference's order: strict < keeps an equal-len tree hit
-            if (len < best.len && len >= sc.tol_f && (!sc.culling || facing(sc, l->prim, sph, r, px, py, pz))) {
-                best.len = len; best.prim = l->prim; best.px = px; best.py = py; best.pz = pz;
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ Rayf load_ray(const rt_ray* __restrict__ rays, int64_t i) {
-    const float* p = reinterpret_cast<const float*>(rays + i);
-    Rayf r; r.ox = p[0]; r.oy = p[1]; r.oz = p[2]; r.dx = p[3]; r.dy = p[4]; r.dz = p[5];
-    return r;
-}
-
-}  // namespace
+#include "trace_device.h"
 
 // ---------------------------------------------------------------------------
 // active: optional per-ray int32 (ray skipped when < 0), used by the renderer

@@ -70,12 +70,15 @@ int rt_photonmap_upload(rt_scene* s, int which, const rt_photon* heap_order, int
     return upload_heap(s, which, heap_order, n);
 }
 
-int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n) {
+int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, float power_scale) {
     if (!s || which < 0 || which > 1 || n < 0 || !photons) return rt_fail(RT_E_INVALID, "rt_photonmap_build: bad argument");
     if (n >= ((int64_t)1 << 31) - 2) return rt_fail(RT_E_LIMIT, "rt_photonmap_build: more than 2^31 photons");
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
     try { rt_photon_balance_host(photons, n); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
+    if (power_scale != 1.0f)                              // ScalePhotonPower(scale, 0, n): slots 0..n-1, photon.cpp:826-833
+        for (int64_t i = 0; i < n; ++i)
+            for (int j = 0; j < 3; ++j) photons[i].power[j] = photons[i].power[j] * power_scale;
     return upload_heap(s, which, photons, n);
 }
 
@@ -153,10 +156,39 @@ int rt_photon_irradiance(rt_scene* s, int which, const float* pos3, const float*
     return RT_OK;
 }
 
-int rt_photonmap_emit(rt_scene* s, int which, int64_t first, int64_t count, uint64_t seed, rt_photon* out, int64_t cap,
+int rt_photonmap_emit(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count, rt_photon* out, int64_t cap,
                       int64_t* nstored) {
-    (void)s; (void)which; (void)first; (void)count; (void)seed; (void)out; (void)cap; (void)nstored;
-    return rt_fail(RT_E_STATE, "rt_photonmap_emit: GPU photon emission is not built yet");
+    if (!s || !e || first < 0 || count < 0 || cap < 0 || !nstored || (cap > 0 && !out))
+        return rt_fail(RT_E_INVALID, "rt_photonmap_emit: bad argument");
+    if (e->which < 0 || e->which > 1 || e->light < 0 || e->light >= s->view.nlights || e->ncaustic_sphere < 0 ||
+        e->ncaustic_sphere > 4 || e->max_depth < 0 || e->max_depth > 6)
+        return rt_fail(RT_E_INVALID, "rt_photonmap_emit: bad emission parameters (map %d, light %d of %d, depth %d)", e->which,
+                       e->light, s->view.nlights, e->max_depth);
+    if (count > ((int64_t)1 << 30)) return rt_fail(RT_E_LIMIT, "rt_photonmap_emit: more than 2^30 emissions in one call");
+    *nstored = 0;
+    if (count == 0) return RT_OK;
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    enum { S_E_COUNTS = 7, S_E_BSUMS = 8, S_E_OFFSETS = 9, S_E_OUT = 10 };
+    const int64_t nb = rtk_scan_blocks_needed(count);
+    void *dc, *db, *doff, *dout = nullptr;
+    RTCHK(s->scratch(S_E_COUNTS, (size_t)count, &dc));
+    RTCHK(s->scratch(S_E_BSUMS, (size_t)nb * 4 + 16, &db));
+    RTCHK(s->scratch(S_E_OFFSETS, (size_t)count * 4, &doff));
+    uint32_t* d_total = (uint32_t*)db + nb;
+    HIPCHK(rtk_emit_photons(s->view, *e, first, count, s->eps_f, s->fast, 0, (uint8_t*)dc, nullptr, nullptr, 0, nullptr), "k_emit_photons");
+    HIPCHK(rtk_scan_flags((const uint8_t*)dc, count, (uint32_t*)db, d_total, nullptr), "scan");
+    HIPCHK(rtk_count_offsets((const uint8_t*)dc, count, (const uint32_t*)db, (uint32_t*)doff, nullptr), "k_count_offsets");
+    uint32_t total = 0;
+    HIPCHK(hipMemcpy(&total, d_total, 4, hipMemcpyDeviceToHost), "read photon count");
+    *nstored = (int64_t)total;
+    const int64_t nw = (int64_t)total < cap ? (int64_t)total : cap;
+    if (nw == 0) return RT_OK;
+    RTCHK(s->scratch(S_E_OUT, (size_t)nw * sizeof(rt_photon), &dout));
+    HIPCHK(rtk_emit_photons(s->view, *e, first, count, s->eps_f, s->fast, 1, nullptr, (const uint32_t*)doff, (rt_photon*)dout, nw,
+                            nullptr), "k_emit_photons");
+    HIPCHK(hipMemcpy(out, dout, (size_t)nw * sizeof(rt_photon), hipMemcpyDeviceToHost), "copy photons");
+    return RT_OK;
 }
 
 }  // extern "C"

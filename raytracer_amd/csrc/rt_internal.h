@@ -142,6 +142,15 @@ hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, cons
                         uint8_t* rgb8, hipStream_t st);
 hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, hipStream_t st);
 
+hipError_t rtk_scan_flags(const uint8_t* flags, int64_t n, uint32_t* block_sums, uint32_t* d_total, hipStream_t st);
+
+// kernels_emit.hip
+hipError_t rtk_emit_photons(const DevSceneView& sc, const rt_emit_params& e, int64_t first, int64_t count, float eps_f,
+                            int fast, int write, uint8_t* d_counts, const uint32_t* d_offsets, rt_photon* d_out, int64_t cap,
+                            hipStream_t st);
+hipError_t rtk_count_offsets(const uint8_t* d_counts, int64_t n, const uint32_t* d_block_offsets, uint32_t* d_offsets,
+                             hipStream_t st);
+
 // kernels_photon.hip
 size_t rtk_knn_lds_bytes(int k);
 hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,

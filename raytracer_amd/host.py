@@ -72,6 +72,18 @@ def default_params(flavour="hw4", **kw):
     return p
 
 
+def final_emit_params(which, seed=1, light=0):
+    """the two emission loops of final.cpp:1053-1123: global photons of colour 3 (:1078), caustic photons of
+    colour 0.2 (:1115) aimed at the hard-coded proxy sphere (:754-758), Nr 2.40, depth 6 (parameter.h:26)."""
+    e = abi.rt_emit_params(); e.which = which; e.light = light
+    e.power[:] = [3.0, 3.0, 3.0] if which == abi.RT_PMAP_GLOBAL else [0.2, 0.2, 0.2]
+    e.start_nr = 2.40; e.max_depth = 6; e.ncaustic_sphere = 1
+    for k, v in enumerate((0.2, -0.3, 0.45, 0.2)):
+        e.caustic_sphere[0][k] = v
+    e.caustic_floor_y = -0.3; e.seed = seed
+    return e
+
+
 def host_flatten(sd: SceneData):
     """The KD-trees exactly as rt_scene_create uploads them, built on the host (no GPU)."""
     L = abi.load()
@@ -160,11 +172,20 @@ class Scene:
         assert a.dtype == abi.photon_dtype
         abi.check(self.L.rt_photonmap_upload(self.h, which, a.ctypes.data, a.shape[0] - 1))
 
-    def photonmap_build(self, which, photons):
+    def photonmap_build(self, which, photons, power_scale=1.0):
+        """photons[1..n] as AddPhoton leaves them -> balanced (+ scaled as final.cpp:1126 does) heap, uploaded."""
         a = np.ascontiguousarray(photons)
         assert a.dtype == abi.photon_dtype
-        abi.check(self.L.rt_photonmap_build(self.h, which, a.ctypes.data, a.shape[0] - 1))
+        abi.check(self.L.rt_photonmap_build(self.h, which, a.ctypes.data, a.shape[0] - 1, float(power_scale)))
         return a
+
+    def photonmap_emit(self, e, first, count, cap=None):
+        """photons stored by emission indices [first, first+count), in emission order (0-based array)."""
+        cap = int(count) * 2 + 64 if cap is None else int(cap)
+        out = np.zeros(cap, abi.photon_dtype)
+        n = C.c_int64(0)
+        abi.check(self.L.rt_photonmap_emit(self.h, C.byref(e), int(first), int(count), out.ctypes.data, cap, C.byref(n)))
+        return out[:min(n.value, cap)], n.value
 
     def photon_knn(self, which, pos, k, max_dist):
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
