@@ -344,6 +344,12 @@ int rt_render_dev(rt_scene* s, const rt_camera* cam, const rt_params* params,
                   uint8_t* d_rgb8, int32_t* d_hit_ids, rt_stats* stats,
                   void* hip_stream);
 
+/* The frame before quantisation: the `color` the pixel loops hold at hw4.cpp:1105-1109 / final.cpp:1158-1176,
+ * float[resx*resy][3], pixel (x,y) at 3*(x + y*resx).  For checking radiance against a tolerance; pixels of
+ * other ranks' tiles keep the caller's values.                                                          */
+int rt_render_radiance(rt_scene* s, const rt_camera* cam, const rt_params* params,
+                       float* radiance, rt_stats* stats);
+
 /* Replaces Camera::GetPixelCenter + normalize (hw4.cpp:268-276,1053-1057):
  * primary rays for pixels [first, first+n) in the reference's loop order
  * (index = x*resy + y, hw4.cpp:1096-1098), offset (ox,oy) added to (x,y).      */

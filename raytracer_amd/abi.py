@@ -86,7 +86,7 @@ SYMBOLS = [
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_irradiance", "rt_photon_irradiance_dev",
-    "rt_render", "rt_render_dev", "rt_generate_primary_dev",
+    "rt_render", "rt_render_dev", "rt_render_radiance", "rt_generate_primary_dev",
 ]
 
 _LIB = None
@@ -135,6 +135,7 @@ def load():
     L.rt_generate_primary_dev.argtypes = [vp, C.POINTER(rt_camera), i64, i64, C.c_float, C.c_float, vp, vp]
     if hasattr(L, "rt_render"):
         L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, vp, C.POINTER(rt_stats)]
+        L.rt_render_radiance.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, C.POINTER(rt_stats)]
         L.rt_render_dev.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, vp, C.POINTER(rt_stats), vp]
     if hasattr(L, "rt_photonmap_upload"):
         L.rt_photonmap_upload.argtypes = [vp, i32, vp, i64]

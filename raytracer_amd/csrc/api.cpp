@@ -67,6 +67,44 @@ static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
     return RT_OK;
 }
 
+// ---- algebra3 on the host (float ops of algebra3.cpp:280-282,295-302,345-347) ----
+namespace {
+struct H3 { float x, y, z; };
+inline H3 h3(const float* p) { return H3{p[0], p[1], p[2]}; }
+inline H3 hadd(H3 a, H3 b) { return H3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline H3 hsub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 hmul(H3 a, float d) { return H3{d * a.x, d * a.y, d * a.z}; }
+inline H3 hdiv(H3 a, float d) { const float di = (float)(1.0 / (double)d); return H3{a.x * di, a.y * di, a.z * di}; }
+inline H3 hnorm(H3 a) { return hdiv(a, std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z)); }
+
+// RectLight::GetSamplePoses, photon.h:90-111; PointLight / SimpleLight: the position itself (:60-64,:121-125)
+void light_samples(const rt_light& l, std::vector<float>& out) {
+    if (l.type != RT_LIGHT_RECT) { out.insert(out.end(), l.pos, l.pos + 3); return; }
+    const H3 dir1 = hnorm(h3(l.dir1)), dir2 = hnorm(h3(l.dir2)), pos = h3(l.pos);
+    const H3 startPos = hsub(hsub(pos, hdiv(hmul(dir1, l.size1), 2.0f)), hdiv(hmul(dir2, l.size2), 2.0f));
+    for (int i = 0; i < l.n1; ++i) {
+        const H3 nowPos = hadd(startPos, hdiv(hmul(hmul(dir1, l.size1), (float)i), (float)l.n1));
+        for (int j = 0; j < l.n2; ++j) {
+            const H3 t = hadd(nowPos, hdiv(hmul(hmul(dir2, l.size2), (float)j), (float)l.n2));
+            out.push_back(t.x); out.push_back(t.y); out.push_back(t.z);
+        }
+    }
+}
+
+// the two triangles the RectL parser adds to lightMeshes, final.cpp:710-731, as v0 / edge1 / edge2
+void light_quad(const rt_light& l, std::vector<float>& out) {
+    const H3 pos = h3(l.pos);
+    const H3 a = hmul(hmul(h3(l.dir1), l.size1), 0.5f), b = hmul(hmul(h3(l.dir2), l.size2), 0.5f);
+    const H3 t[2][3] = {{hsub(hsub(pos, a), b), hsub(hadd(pos, a), b), hadd(hsub(pos, a), b)},
+                        {hadd(hadd(pos, a), b), hsub(hadd(pos, a), b), hadd(hsub(pos, a), b)}};
+    for (int k = 0; k < 2; ++k) {
+        const H3 e1 = hsub(t[k][1], t[k][0]), e2 = hsub(t[k][2], t[k][0]);
+        const float f[9] = {t[k][0].x, t[k][0].y, t[k][0].z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z};
+        out.insert(out.end(), f, f + 9);
+    }
+}
+}  // namespace
+
 static bool is_gfx950(int dev) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
@@ -140,6 +178,18 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         memcpy(o.dir1, l.dir1, 12); o.size1 = l.size1; memcpy(o.dir2, l.dir2, 12); o.size2 = l.size2;
     }
     s->host_lights.assign(d->lights, d->lights + d->nlight);
+    std::vector<float> lsamples, ltris;
+    std::vector<int32_t> lfirst;
+    for (int i = 0; i < d->nlight; ++i) {
+        const rt_light& l = d->lights[i];
+        if (l.type == RT_LIGHT_RECT && (l.n1 < 0 || l.n2 < 0 || (int64_t)l.n1 * l.n2 > 1 << 20)) {
+            delete s; return rt_fail(RT_E_LIMIT, "light %d: %d x %d samples", i, l.n1, l.n2);
+        }
+        lfirst.push_back((int32_t)(lsamples.size() / 3));
+        light_samples(l, lsamples);
+        if (l.type == RT_LIGHT_RECT) light_quad(l, ltris);
+    }
+    lfirst.push_back((int32_t)(lsamples.size() / 3));
     std::vector<int32_t> pmat(d->prim_material, d->prim_material + d->nprim);
     std::vector<uint8_t> ptype(d->prim_type, d->prim_type + d->nprim);
 
@@ -156,7 +206,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!rc) rc = upload(s, ptype, &v.prim_type);
     if (!rc) rc = upload(s, mats, &v.materials);
     if (!rc) rc = upload(s, lights, &v.lights);
+    if (!rc) rc = upload(s, lsamples, &v.light_samples);
+    if (!rc) rc = upload(s, lfirst, &v.light_sample_first);
+    if (!rc) rc = upload(s, ltris, &v.light_tris);
     if (rc) { rt_scene_destroy(s); return rc; }
+    v.nlight_samples = (int32_t)(lsamples.size() / 3);
+    v.nlight_tris = (int32_t)(ltris.size() / 9);
     v.nnodes = (int32_t)flat.nodes[7].size();
     v.nloose = (int32_t)flat.loose.size();
     v.nlights = d->nlight;

@@ -320,6 +320,15 @@ k_finalize(const int32_t* __restrict__ pix0, int64_t n, const float* __restrict_
 }
 
 extern "C" __global__ void __launch_bounds__(256)
+k_copy_radiance(const int32_t* __restrict__ pix0, int64_t n, const float* __restrict__ accum, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix0[i];
+    if (p < 0) return;
+    out[3 * (size_t)p] = accum[3 * (size_t)p]; out[3 * (size_t)p + 1] = accum[3 * (size_t)p + 1]; out[3 * (size_t)p + 2] = accum[3 * (size_t)p + 2];
+}
+
+extern "C" __global__ void __launch_bounds__(256)
 k_zero_pixels(const int32_t* __restrict__ pix0, int64_t n, float* __restrict__ accum) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -387,6 +396,12 @@ hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, cons
                         uint8_t* rgb8, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_finalize, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum, hit_any, bg[0], bg[1], bg[2], rgb8);
+    return hipGetLastError();
+}
+
+hipError_t rtk_copy_radiance(const int32_t* pix0, int64_t n, const float* accum, float* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_radiance, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum, out);
     return hipGetLastError();
 }
 

@@ -97,25 +97,6 @@ k_trace_work(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __
     }
 }
 
-// Camera::GetPixelCenter + normalize, hw4.cpp:268-276, 1053-1056.
-__device__ __forceinline__ void primary_ray(const rt_camera& cam, float fx, float fy, float* o6) {
-    const float wx = cam.corners[1][0] - cam.corners[0][0], wy = cam.corners[1][1] - cam.corners[0][1],
-                wz = cam.corners[1][2] - cam.corners[0][2];
-    const float hx = cam.corners[0][0] - cam.corners[2][0], hy = cam.corners[0][1] - cam.corners[2][1],
-                hz = cam.corners[0][2] - cam.corners[2][2];
-    const float pixelWidth = sqrt_rn(wx * wx + wy * wy + wz * wz) / ((float)cam.resx);
-    const float pixelHeight = sqrt_rn(hx * hx + hy * hy + hz * hz) / ((float)cam.resy);
-    const float a = 0.5f * pixelWidth, b = 0.5f * pixelHeight, c = fx * pixelWidth, d = fy * pixelHeight;
-    float p[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        p[k] = (((cam.corners[0][k] + a * cam.xaxis[k]) + b * cam.yaxis[k]) + c * cam.xaxis[k]) + d * cam.yaxis[k];
-    float dx = p[0] - cam.center[0], dy = p[1] - cam.center[1], dz = p[2] - cam.center[2];
-    normalize3(dx, dy, dz);
-    o6[0] = cam.center[0]; o6[1] = cam.center[1]; o6[2] = cam.center[2];
-    o6[3] = dx; o6[4] = dy; o6[5] = dz;
-}
-
 // rays in the reference's loop order: index = x*resy + y (hw4.cpp:1096-1098)
 extern "C" __global__ void __launch_bounds__(256)
 k_generate_linear(rt_camera cam, int64_t first, int64_t n, float ox, float oy, rt_ray* __restrict__ rays) {

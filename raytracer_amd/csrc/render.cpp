@@ -18,6 +18,11 @@ static_assert(S_WORK < RT_NSCRATCH, "not enough scratch slots");
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 
+}  // namespace
+
+int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* d_rgb8, int32_t* d_hit_ids,
+                       rt_stats* stats, hipStream_t st);                                           // render_photon.cpp
+
 // micro-tiles (8x8 pixels) of the tiles this rank owns; tiles are tile_size^2 pixels,
 // numbered row-major, dealt round-robin over ranks.
 void rank_microtiles(const rt_camera& cam, const rt_params& p, std::vector<int32_t>& out) {
@@ -39,9 +44,12 @@ void rank_microtiles(const rt_camera& cam, const rt_params& p, std::vector<int32
     }
 }
 
+namespace {
+
 int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* d_rgb8, int32_t* d_hit_ids,
                 rt_stats* stats, hipStream_t st) {
-    if (p->mode != RT_RENDER_WHITTED) return rt_fail(RT_E_INVALID, "rt_render: mode %d is not built yet", p->mode);
+    if (p->mode == RT_RENDER_PHOTON) return render_photon_impl(s, cam, p, d_rgb8, d_hit_ids, stats, st);
+    if (p->mode != RT_RENDER_WHITTED) return rt_fail(RT_E_INVALID, "rt_render: unknown mode %d", p->mode);
     const int64_t npix = (int64_t)cam->resx * cam->resy;
     std::vector<int32_t> tiles;
     rank_microtiles(*cam, *p, tiles);
@@ -150,6 +158,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         n = (int64_t)total;
     }
     HIPCHK(rtk_finalize((const int32_t*)pix0, n0, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8, st), "k_finalize");
+    if (s->d_radiance_out) HIPCHK(rtk_copy_radiance((const int32_t*)pix0, n0, (const float*)accum, s->d_radiance_out, st), "k_copy_radiance");
     if (stats) {
         HIPCHK(hipEventRecord(ev1, st), "event");
         unsigned long long h[8], hw[8] = {};
@@ -196,6 +205,23 @@ extern "C" int rt_render_dev(rt_scene* s, const rt_camera* cam, const rt_params*
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
     return render_impl(s, cam, p, d_rgb8, d_hit_ids, stats, (hipStream_t)stream);
+}
+
+extern "C" int rt_render_radiance(rt_scene* s, const rt_camera* cam, const rt_params* p, float* radiance, rt_stats* stats) {
+    RTCHK(check_args(s, cam, p, radiance));
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    const size_t npix = (size_t)cam->resx * cam->resy;
+    void *d_rgb, *d_rad;
+    RTCHK(s->scratch(0, npix * 3, &d_rgb));
+    RTCHK(s->scratch(1, npix * 12, &d_rad));
+    HIPCHK(hipMemcpy(d_rad, radiance, npix * 12, hipMemcpyHostToDevice), "copy radiance in");   // other ranks' pixels stay
+    s->d_radiance_out = (float*)d_rad;
+    const int rc = render_impl(s, cam, p, (uint8_t*)d_rgb, nullptr, stats, nullptr);
+    s->d_radiance_out = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(radiance, d_rad, npix * 12, hipMemcpyDeviceToHost), "copy radiance out");
+    return RT_OK;
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* rgb8, int32_t* hit_ids,

@@ -84,6 +84,10 @@ struct DevSceneView {       // passed by value to kernels
     const float* prim_geom;     // [nprim][4] sphere centre+radius (spheres only)
     const DevMaterial* materials;
     const DevLight* lights; int32_t nlights;
+    // rect-light sampling of the photon renderer: GetSamplePoses (photon.h:90-111) per light, concatenated;
+    // light l owns samples [light_sample_first[l], light_sample_first[l+1]); lightMeshes (final.cpp:710-731)
+    const float* light_samples; const int32_t* light_sample_first; int32_t nlight_samples;
+    const float* light_tris; int32_t nlight_tris;      // [nlight_tris][9]: v0, edge1, edge2
     float tol_f;                // smallest float t with (double)t > tolerance_depth  <=>  len >= tol_f
     int32_t culling;
     float shadow_bias, refract_bias;
@@ -140,6 +144,7 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
                                 float* onr, unsigned long long* counters, hipStream_t st);
 hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
                         uint8_t* rgb8, hipStream_t st);
+hipError_t rtk_copy_radiance(const int32_t* pix0, int64_t n, const float* accum, float* out, hipStream_t st);
 hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, hipStream_t st);
 
 hipError_t rtk_scan_flags(const uint8_t* flags, int64_t n, uint32_t* block_sums, uint32_t* d_total, hipStream_t st);
@@ -150,6 +155,39 @@ hipError_t rtk_emit_photons(const DevSceneView& sc, const rt_emit_params& e, int
                             hipStream_t st);
 hipError_t rtk_count_offsets(const uint8_t* d_counts, int64_t n, const uint32_t* d_block_offsets, uint32_t* d_offsets,
                              hipStream_t st);
+
+// kernels_pm.hip (photon-mapping renderer)
+hipError_t rtk_pm_generate(const DevSceneView& sc, const rt_camera& cam, const int32_t* d_tiles, int64_t tile0, int64_t nt,
+                           int ntap, int use_filter, float eps_f, rt_ray* rays, int32_t* sid, float* w, uint32_t* code,
+                           int32_t* pixmap, uint8_t* white, uint8_t* hit_any, int32_t* hit_ids, float* accum,
+                           unsigned long long* ctr, hipStream_t st);
+hipError_t rtk_pm_shade(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* sid, int64_t n,
+                        int ntap, int depth0, int spawn, float start_nr, uint8_t* flags, float* nrm, float* nrmL,
+                        float* qpos, uint8_t* hit_any, int32_t* hit_ids, const int32_t* pixmap, unsigned long long* ctr,
+                        hipStream_t st);
+hipError_t rtk_pm_shadow(const DevSceneView& sc, const rt_hit* hits, const int32_t* sid, const float* nrmL, int64_t n,
+                         int S, float eps_f, int fast, uint8_t* occ, unsigned long long* ctr, hipStream_t st);
+hipError_t rtk_pm_direct(const DevSceneView& sc, const rt_hit* hits, const int32_t* sid, const float* w, const float* nrmL,
+                         int64_t n, int S, const uint8_t* occ, const float* caustic, const float eye[3], float* contrib,
+                         hipStream_t st);
+hipError_t rtk_pm_gather_spawn(const rt_hit* hits, const int32_t* sid, const float* w, const uint32_t* code,
+                               const float* nrmL, const int32_t* pixmap, int64_t n, int G, int ntap, uint64_t seed,
+                               rt_ray* grays, int32_t* gsid, float* gw, hipStream_t st);
+hipError_t rtk_gi_shade(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* sid, int64_t n,
+                        int last, float start_nr, uint8_t* flags, float* qpos, float* qnrm, float* kd,
+                        unsigned long long* ctr, hipStream_t st);
+hipError_t rtk_gi_contrib(const int32_t* sid, const float* w, const float* kd, const float* irr, int64_t n, float inv_g,
+                          float* contrib, hipStream_t st);
+hipError_t rtk_pm_spawn(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* sid, const float* w,
+                        const uint32_t* code, const uint8_t* flags, int64_t nflags, uint32_t* block_sums, uint32_t* d_total,
+                        float start_nr, rt_ray* orays, int32_t* osid, float* ow, uint32_t* ocode, unsigned long long* ctr,
+                        hipStream_t st);
+hipError_t rtk_gi_spawn(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* sid, const float* w,
+                        const uint8_t* flags, int64_t nflags, uint32_t* block_sums, uint32_t* d_total, float start_nr,
+                        rt_ray* orays, int32_t* osid, float* ow, hipStream_t st);
+hipError_t rtk_pm_finalize(const int32_t* pixmap, int64_t nps, int ntap, int use_filter, const float* accum,
+                           const uint8_t* white, const uint8_t* hit_any, const float bg[3], uint8_t* rgb8, float* radiance,
+                           hipStream_t st);
 
 // kernels_photon.hip
 size_t rtk_knn_lds_bytes(int k);

@@ -30,6 +30,7 @@ struct rt_scene {
     void* scratch_ptr[RT_NSCRATCH] = {};
     size_t scratch_cap[RT_NSCRATCH] = {};
     PhotonMapDev pmap[2];
+    float* d_radiance_out = nullptr;  // set for the duration of rt_render_radiance: [resx*resy][3] un-quantised colour
     float* d_dir_tables = nullptr;    // cosTheta, sinTheta, cosPhi, sinPhi [4][256] (photon.cpp:24-27)
 
     int dev_alloc(void** p, size_t bytes);

@@ -167,6 +167,29 @@ class Scene:
                                    None if ids is None else ids.ctypes.data, C.byref(st)))
         return rgb.reshape(cam.resy, cam.resx, 3), ids, st
 
+    def photonmap_emit_until(self, e, target, batch=None):
+        """The `while (stored < max)` loops of final.cpp:1057 / :1090: emission indices 0,1,2,... in batches until
+        `target` photons are stored; returns the first `target` of them in emission order (what AddPhoton keeps,
+        photon.cpp:837) and the number of emission indices consumed."""
+        batch = int(batch or max(4096, target // 4))
+        parts, have, first = [], 0, 0
+        while have < target:
+            ph, n = self.photonmap_emit(e, first, batch, cap=2 * batch + 64)
+            if n > ph.size:
+                raise abi.RtError(abi.RT_E_LIMIT if hasattr(abi, "RT_E_LIMIT") else -4, "emission batch overflowed its buffer")
+            parts.append(ph); have += ph.size; first += batch
+            if first > 1000 * max(target, 1) + 10 * batch:
+                raise RuntimeError("photon emission stores (almost) nothing: no target reachable")
+        out = np.concatenate(parts)[:target] if parts else np.zeros(0, abi.photon_dtype)
+        return out, first
+
+    def render_radiance(self, cam, params):
+        """the un-quantised frame (float [resy][resx][3])"""
+        rad = np.zeros(cam.resx * cam.resy * 3, np.float32)
+        st = abi.rt_stats()
+        abi.check(self.L.rt_render_radiance(self.h, C.byref(cam), C.byref(params), rad.ctypes.data, C.byref(st)))
+        return rad.reshape(cam.resy, cam.resx, 3), st
+
     def photonmap_upload(self, which, heap_order):
         a = np.ascontiguousarray(heap_order)
         assert a.dtype == abi.photon_dtype

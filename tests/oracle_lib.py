@@ -174,6 +174,15 @@ class OracleScene:
                                   None if rad is None else rad.ctypes.data)
         return rgb.reshape(cam.resy, cam.resx, 3), ids, rad
 
+    def render_photon(self, cam, params, gheap, cheap):
+        """PhotonMappingImageSynthesis' pixel loop (final.cpp:1146-1202) over the given balanced maps"""
+        n = cam.resx * cam.resy
+        rgb = np.zeros(n * 3, np.uint8); ids = np.zeros(n, np.int32); rad = np.zeros((n, 3), np.float32)
+        g = np.ascontiguousarray(gheap); c = np.ascontiguousarray(cheap)
+        self.L.orc_render_photon(self.h, C.byref(cam), C.byref(params), g.ctypes.data, g.shape[0] - 1, c.ctypes.data,
+                                 c.shape[0] - 1, rgb.ctypes.data, ids.ctypes.data, rad.ctypes.data)
+        return rgb.reshape(cam.resy, cam.resx, 3), ids, rad.reshape(cam.resy, cam.resx, 3)
+
 
 def oracle_shadow_rays(points, light, normals, bias=1e-4):
     points = np.ascontiguousarray(points, np.float32); normals = np.ascontiguousarray(normals, np.float32)
