@@ -310,6 +310,10 @@ typedef struct rt_emit_params {
  * behind, ready for rt_photonmap_build.                                                         */
 int rt_photonmap_emit(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count,
                       rt_photon* out, int64_t cap, int64_t* nstored);
+/* the same into a device buffer on the scene's GPU (what a rank hands to the RCCL all-gather that assembles the
+ * map); runs on the caller's stream and synchronises it once to learn *nstored.                    */
+int rt_photonmap_emit_dev(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count,
+                          rt_photon* d_out, int64_t cap, int64_t* nstored, void* hip_stream);
 
 /* Replaces PhotonMap::LocatePhoton (photon.cpp:53-131): for each query the k
  * nearest photons within maxDist.  idx: [q][k] heap-array indices (1-based as

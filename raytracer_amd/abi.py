@@ -84,7 +84,7 @@ SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_set_option",
     "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
-    "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit",
+    "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit", "rt_photonmap_emit_dev",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_irradiance", "rt_photon_irradiance_dev",
     "rt_render", "rt_render_dev", "rt_render_radiance", "rt_generate_primary_dev",
 ]
@@ -141,6 +141,7 @@ def load():
         L.rt_photonmap_upload.argtypes = [vp, i32, vp, i64]
         L.rt_photonmap_build.argtypes = [vp, i32, vp, i64, C.c_float]
         L.rt_photonmap_emit.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64)]
+        L.rt_photonmap_emit_dev.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64), vp]
         L.rt_photon_knn.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp]
         L.rt_photon_knn_dev.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]
         L.rt_photon_irradiance.argtypes = [vp, i32, vp, vp, i64, i32, C.c_float, vp]

@@ -156,8 +156,8 @@ int rt_photon_irradiance(rt_scene* s, int which, const float* pos3, const float*
     return RT_OK;
 }
 
-int rt_photonmap_emit(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count, rt_photon* out, int64_t cap,
-                      int64_t* nstored) {
+static int emit_impl(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count, rt_photon* out, int out_is_device,
+                     int64_t cap, int64_t* nstored, hipStream_t st) {
     if (!s || !e || first < 0 || count < 0 || cap < 0 || !nstored || (cap > 0 && !out))
         return rt_fail(RT_E_INVALID, "rt_photonmap_emit: bad argument");
     if (e->which < 0 || e->which > 1 || e->light < 0 || e->light >= s->view.nlights || e->ncaustic_sphere < 0 ||
@@ -176,19 +176,33 @@ int rt_photonmap_emit(rt_scene* s, const rt_emit_params* e, int64_t first, int64
     RTCHK(s->scratch(S_E_BSUMS, (size_t)nb * 4 + 16, &db));
     RTCHK(s->scratch(S_E_OFFSETS, (size_t)count * 4, &doff));
     uint32_t* d_total = (uint32_t*)db + nb;
-    HIPCHK(rtk_emit_photons(s->view, *e, first, count, s->eps_f, s->fast, 0, (uint8_t*)dc, nullptr, nullptr, 0, nullptr), "k_emit_photons");
-    HIPCHK(rtk_scan_flags((const uint8_t*)dc, count, (uint32_t*)db, d_total, nullptr), "scan");
-    HIPCHK(rtk_count_offsets((const uint8_t*)dc, count, (const uint32_t*)db, (uint32_t*)doff, nullptr), "k_count_offsets");
+    // pass 0: how many photons does each emission index store; scan -> where they go
+    HIPCHK(rtk_emit_photons(s->view, *e, first, count, s->eps_f, s->fast, 0, (uint8_t*)dc, nullptr, nullptr, 0, st), "k_emit_photons");
+    HIPCHK(rtk_scan_flags((const uint8_t*)dc, count, (uint32_t*)db, d_total, st), "scan");
+    HIPCHK(rtk_count_offsets((const uint8_t*)dc, count, (const uint32_t*)db, (uint32_t*)doff, st), "k_count_offsets");
     uint32_t total = 0;
-    HIPCHK(hipMemcpy(&total, d_total, 4, hipMemcpyDeviceToHost), "read photon count");
+    HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st), "read photon count");
+    HIPCHK(hipStreamSynchronize(st), "sync");
     *nstored = (int64_t)total;
     const int64_t nw = (int64_t)total < cap ? (int64_t)total : cap;
     if (nw == 0) return RT_OK;
-    RTCHK(s->scratch(S_E_OUT, (size_t)nw * sizeof(rt_photon), &dout));
+    if (out_is_device) dout = out;
+    else RTCHK(s->scratch(S_E_OUT, (size_t)nw * sizeof(rt_photon), &dout));
+    // pass 1: the same walks again, photons written in emission order
     HIPCHK(rtk_emit_photons(s->view, *e, first, count, s->eps_f, s->fast, 1, nullptr, (const uint32_t*)doff, (rt_photon*)dout, nw,
-                            nullptr), "k_emit_photons");
-    HIPCHK(hipMemcpy(out, dout, (size_t)nw * sizeof(rt_photon), hipMemcpyDeviceToHost), "copy photons");
+                            st), "k_emit_photons");
+    if (!out_is_device) HIPCHK(hipMemcpy(out, dout, (size_t)nw * sizeof(rt_photon), hipMemcpyDeviceToHost), "copy photons");
     return RT_OK;
+}
+
+int rt_photonmap_emit(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count, rt_photon* out, int64_t cap,
+                      int64_t* nstored) {
+    return emit_impl(s, e, first, count, out, 0, cap, nstored, nullptr);
+}
+
+int rt_photonmap_emit_dev(rt_scene* s, const rt_emit_params* e, int64_t first, int64_t count, rt_photon* d_out, int64_t cap,
+                          int64_t* nstored, void* stream) {
+    return emit_impl(s, e, first, count, d_out, 1, cap, nstored, (hipStream_t)stream);
 }
 
 }  // extern "C"

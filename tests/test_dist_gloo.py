@@ -41,3 +41,21 @@ def test_gather_to_rank0_over_gloo(world):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["assembled_ok"] and j["n_gpus"] == world and sum(j["pixels_per_rank"]) == j["frame"][0] * j["frame"][1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_emission_allgather_over_gloo(world):
+    """SURVEY 8e's one exchange step: emission sharded by emission index, counts + payload all-gathered, every rank
+    ends with the array a single process emits (raytracer_amd/dist.py, the code the GPU ranks run over RCCL)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29560 + world),
+           os.path.join(ROOT, "tests", "dist_emit_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["world"] == world
+    for which, target in (("0", 5000), ("1", 300)):
+        res = j["results"][which]
+        assert res["n"] == target and res["same_everywhere"] and res["equals_single_process"], res
+        assert res["allgather_bytes"] > 0
