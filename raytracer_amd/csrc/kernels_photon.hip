@@ -16,9 +16,16 @@
 // reference's array/heap code statement by statement, hence np.index comes
 // out in the reference's order and the irradiance sum adds in its order.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "rt_internal.h"
 
 #define KNN_LEVELS 32
+
+// Queries per 64-lane wave.  The candidate heaps (808 B per query at k = 100) are what limits residency: with 64
+// queries a wave needs 62 KB of LDS and a CU holds two waves (two of its four SIMDs idle, nothing to hide LDS or
+// memory latency behind).  Fewer queries per wave = more resident waves for the same number of queries in flight,
+// and fewer lanes waiting for the one lane that is re-heapifying.  Lanes >= KNN_QL exit at once.
+// KNN_QL is a template parameter of the kernel; rtk_photon_knn picks the instantiation (RT_KNN_QL overrides).
 
 namespace {
 
@@ -29,11 +36,13 @@ struct KnnLds {
     float* s2;      // [KNN_LEVELS][64] photon distance^2 per level
 };
 
-// the "we found a photon" block of LocatePhoton, photon.cpp:79-128
-__device__ __forceinline__ void consider(const KnnLds& L, int t, int k, int& found, int& got_heap, int index, float dist2) {
-#define HD(j) L.hd[(j) * 64 + t]
-#define HI(j) L.hi[(j) * 64 + t]
-    if (!(dist2 < HD(0))) return;
+// the "we found a photon" block of LocatePhoton, photon.cpp:79-128.  r2 mirrors np.dist2[0] in a register.
+template <int KNN_QL>
+__device__ __forceinline__ void consider(const KnnLds& L, int t, int k, int& found, int& got_heap, float& r2, int index,
+                                         float dist2) {
+#define HD(j) L.hd[(j) * KNN_QL + t]
+#define HI(j) L.hi[(j) * KNN_QL + t]
+    if (!(dist2 < r2)) return;
     if (found < k) {
         ++found;
         HD(found) = dist2; HI(found) = index;
@@ -59,83 +68,97 @@ __device__ __forceinline__ void consider(const KnnLds& L, int t, int k, int& fou
     }
     parent = 1; j = 2;
     while (j <= found) {
-        if (j < found && HD(j) < HD(j + 1)) ++j;
-        if (dist2 > HD(j)) break;
-        HD(parent) = HD(j); HI(parent) = HI(j);
+        float dj = HD(j);
+        if (j < found) { const float dj1 = HD(j + 1); if (dj < dj1) { ++j; dj = dj1; } }
+        if (dist2 > dj) break;
+        HD(parent) = dj; HI(parent) = HI(j);
         parent = j; j += j;
     }
     HI(parent) = index; HD(parent) = dist2;
-    HD(0) = HD(1);
+    r2 = HD(1);
 #undef HD
 #undef HI
 }
 
+// LocatePhoton's recursion (photon.cpp:53-131) unrolled over the implicit heap numbering.  Every trip of the outer
+// loop fetches exactly one photon record per lane (all lanes keep a load in flight); a lane that reached a node
+// without children then climbs -- candidates come from the per-level stash in LDS, no memory traffic -- until a far
+// subtree has to be entered or the root is done.  The candidates reach `consider` in the reference's order
+// (near subtree, far subtree, the node itself).
+template <int KNN_QL>
 __device__ __forceinline__ void locate(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const KnnLds& L,
-                                       int t, int k, float qx, float qy, float qz, int& found) {
+                                       int t, int k, float qx, float qy, float qz, float& r2, int& found) {
     int got_heap = 0;
     found = 0;
-    if (n < 1) return;
-    int64_t idx = 1;
-    for (;;) {
-        // ---- descend from idx to a node without children, stashing the path ----
-        float dist2;
+    bool done = n < 1;
+    unsigned idx = 1;
+    const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
+    while (__ballot(!done) != 0ull) {
+        if (done) continue;
+        const float4 rec = *reinterpret_cast<const float4*>(ph + idx);           // pos.xyz + packed (16 B record)
+        float d1 = rec.x - qx;
+        float dist2 = d1 * d1;
+        d1 = rec.y - qy; dist2 += d1 * d1;
+        d1 = rec.z - qz; dist2 += d1 * d1;
+        if (idx < uhalf) {
+            const int plane = __float_as_int(rec.w) & 3;
+            const float pp = plane == 0 ? rec.x : (plane == 1 ? rec.y : rec.z);
+            const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
+            const float dist1 = qp - pp;
+            const int lvl = 31 - __builtin_clz(idx);
+            L.s1[lvl * KNN_QL + t] = dist1; L.s2[lvl * KNN_QL + t] = dist2;
+            idx = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
+            continue;
+        }
+        int cidx = (int)idx;
+        float cd2 = dist2;
         for (;;) {
-            const float4 rec = *reinterpret_cast<const float4*>(ph + idx);       // pos.xyz + packed
-            float d1 = rec.x - qx;
-            dist2 = d1 * d1;
-            d1 = rec.y - qy; dist2 += d1 * d1;
-            d1 = rec.z - qz; dist2 += d1 * d1;
-            if (idx < half) {
-                const int plane = __float_as_int(rec.w) & 3;
-                const float pp = plane == 0 ? rec.x : (plane == 1 ? rec.y : rec.z);
-                const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
-                const float dist1 = qp - pp;
-                const int lvl = 63 - __builtin_clzll((unsigned long long)idx);
-                L.s1[lvl * 64 + t] = dist1; L.s2[lvl * 64 + t] = dist2;
-                idx = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
-            } else break;
-        }
-        consider(L, t, k, found, got_heap, (int)idx, dist2);
-        // ---- ascend until a far subtree has to be entered ----
-        bool descend = false;
-        while (idx > 1) {
-            const int64_t child = idx;
+            consider<KNN_QL>(L, t, k, found, got_heap, r2, cidx, cd2);
+            if (idx == 1) { done = true; break; }
+            const unsigned child = idx;
             idx >>= 1;
-            const int lvl = 63 - __builtin_clzll((unsigned long long)idx);
-            const float dist1 = L.s1[lvl * 64 + t];
-            const int64_t near = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
-            if (child == near && dist1 * dist1 < L.hd[t]) { idx = near ^ 1; descend = true; break; }
-            consider(L, t, k, found, got_heap, (int)idx, L.s2[lvl * 64 + t]);
+            const int lvl = 31 - __builtin_clz(idx);
+            const float dist1 = L.s1[lvl * KNN_QL + t];
+            const unsigned near = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
+            if (child == near && dist1 * dist1 < r2) { idx = near ^ 1u; break; }
+            cidx = (int)idx; cd2 = L.s2[lvl * KNN_QL + t];
         }
-        if (!descend) return;
     }
 }
 
 }  // namespace
 
 // mode 0: write idx/dist2/found/radius2.   mode 1: irradiance rgb.
-extern "C" __global__ void __launch_bounds__(64)
+template <int KNN_QL>
+__global__ void __launch_bounds__(64)
 k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
              const float* __restrict__ nrm3, int64_t q, int k, float maxDist, int mode,
              int32_t* __restrict__ out_idx, float* __restrict__ out_d2, int32_t* __restrict__ out_found,
-             float* __restrict__ out_r2, float* __restrict__ out_rgb, const float* __restrict__ tables) {
+             float* __restrict__ out_r2, float* __restrict__ out_rgb, const float* __restrict__ tables, int xcd_map) {
     extern __shared__ float lds[];
     KnnLds L;
     L.hd = lds;
-    L.hi = reinterpret_cast<int*>(lds + (k + 1) * 64);
-    L.s1 = lds + 2 * (k + 1) * 64;
-    L.s2 = L.s1 + KNN_LEVELS * 64;
+    L.hi = reinterpret_cast<int*>(lds + (k + 1) * KNN_QL);
+    L.s1 = lds + 2 * (k + 1) * KNN_QL;
+    L.s2 = L.s1 + KNN_LEVELS * KNN_QL;
     const int t = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * 64 + t;
-    if (i >= q) return;
+    // xcd_map: give every XCD (blocks are dealt round-robin to the 8 XCDs) one contiguous range of the queries.
+    // Measured SLOWER (287 ms vs 225 ms): the cost of a query varies over the scene and the ranges finish at
+    // different times; the interleaved default balances the XCDs and the shared nodes sit in the Infinity Cache.
+    // (the grid is a multiple of 8 blocks: block b -> logical block (b % 8) * (grid / 8) + b / 8, a bijection)
+    const unsigned per = gridDim.x >> 3;
+    const unsigned lb = xcd_map ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t i = (int64_t)lb * KNN_QL + t;
+    if (t >= KNN_QL || i >= q) return;
     const float qx = pos3[3 * i], qy = pos3[3 * i + 1], qz = pos3[3 * i + 2];
-    L.hd[t] = maxDist * maxDist;                                   // np.dist2[0], photon.cpp:405
+    float r2 = maxDist * maxDist;                                  // np.dist2[0], photon.cpp:405
     int found;
-    locate(ph, n, half, L, t, k, qx, qy, qz, found);
+    locate<KNN_QL>(ph, n, half, L, t, k, qx, qy, qz, r2, found);
+    L.hd[t] = r2;
     if (mode == 0) {
         for (int j = 0; j < k; ++j) {
-            out_idx[i * k + j] = j < found ? L.hi[(j + 1) * 64 + t] : -1;
-            out_d2[i * k + j] = j < found ? L.hd[(j + 1) * 64 + t] : 0.0f;
+            out_idx[i * k + j] = j < found ? L.hi[(j + 1) * KNN_QL + t] : -1;
+            out_d2[i * k + j] = j < found ? L.hd[(j + 1) * KNN_QL + t] : 0.0f;
         }
         out_found[i] = found;
         if (out_r2) out_r2[i] = L.hd[t];
@@ -145,12 +168,16 @@ k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const fl
             const float nx = nrm3[3 * i], ny = nrm3[3 * i + 1], nz = nrm3[3 * i + 2];
             const float* cosT = tables; const float* sinT = tables + 256;
             const float* cosP = tables + 512; const float* sinP = tables + 768;
+            const DevPhotonPow* pw = reinterpret_cast<const DevPhotonPow*>(ph + (n + 1));
             for (int j = 1; j <= found; ++j) {
-                const DevPhoton* p = ph + L.hi[j * 64 + t];
-                const unsigned pk = p->packed;
+                const int pi = L.hi[j * KNN_QL + t];
+                const unsigned pk = ph[pi].packed;
                 const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
                 const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
-                if ((dx * nx + dy * ny + dz * nz) < 0.0f) { r += p->power[0]; g += p->power[1]; b += p->power[2]; }
+                if ((dx * nx + dy * ny + dz * nz) < 0.0f) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(pw + pi);
+                    r += w4.x; g += w4.y; b += w4.z;
+                }
             }
             const float tmp = (float)(((double)1.0f / 3.141592) / (double)L.hd[t]);   // (1.0f/PI)/(np.dist2[0])
             r *= tmp; g *= tmp; b *= tmp;
@@ -159,18 +186,45 @@ k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const fl
     }
 }
 
-size_t rtk_knn_lds_bytes(int k) { return (size_t)(2 * (k + 1) + 2 * KNN_LEVELS) * 64 * 4; }
+static int knn_ql() {
+    static int ql = 0;
+    if (!ql) {
+        ql = 4;      // measured on MI355X, 10 M photons, k = 100: 64 -> 509 ms, 32 -> 432, 16 -> 314, 8 -> 241, 4 -> 226, 2 -> 296
+        if (const char* e = getenv("RT_KNN_QL")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ql = v; }
+    }
+    return ql;
+}
+
+size_t rtk_knn_lds_bytes(int k) { return (size_t)(2 * (k + 1) + 2 * KNN_LEVELS) * knn_ql() * 4; }
+
+template <int QL>
+static hipError_t launch_knn(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
+                             int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
+                             float* d_r2, float* d_rgb, const float* d_tables, hipStream_t st) {
+    const size_t lds = (size_t)(2 * (k + 1) + 2 * KNN_LEVELS) * QL * 4;
+    if (lds > 64 * 1024) {   // per current device; cheap enough to repeat
+        hipError_t e = hipFuncSetAttribute((const void*)k_photon_knn<QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned grid = (unsigned)((((q + QL - 1) / QL) + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_photon_knn<QL>, dim3(grid), dim3(64), lds, st, ph, n, half, d_pos3, d_nrm3, q,
+                       k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, getenv("RT_KNN_XCD") ? atoi(getenv("RT_KNN_XCD")) : 0);
+    return hipGetLastError();
+}
 
 hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
                           int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
                           float* d_r2, float* d_rgb, const float* d_tables, hipStream_t st) {
     if (q <= 0) return hipSuccess;
-    const size_t lds = rtk_knn_lds_bytes(k);
-    if (lds > 64 * 1024) {   // per current device; cheap enough to repeat
-        hipError_t e = hipFuncSetAttribute((const void*)k_photon_knn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+#define KNN_ARGS ph, n, half, d_pos3, d_nrm3, q, k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, st
+    switch (knn_ql()) {
+        case 2: return launch_knn<2>(KNN_ARGS);
+        case 4: return launch_knn<4>(KNN_ARGS);
+        case 8: return launch_knn<8>(KNN_ARGS);
+        case 32: return launch_knn<32>(KNN_ARGS);
+        case 64: return launch_knn<64>(KNN_ARGS);
+        case 16: return launch_knn<16>(KNN_ARGS);
+        default: return launch_knn<4>(KNN_ARGS);
     }
-    hipLaunchKernelGGL(k_photon_knn, dim3((unsigned)((q + 63) / 64)), dim3(64), lds, st, ph, n, half, d_pos3, d_nrm3, q, k,
-                       maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables);
-    return hipGetLastError();
+#undef KNN_ARGS
 }

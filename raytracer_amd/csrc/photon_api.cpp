@@ -40,19 +40,21 @@ int check_map(rt_scene* s, int which, int k, const char* fn) {
 int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
     PhotonMapDev& m = s->pmap[which];
     if (m.d_photons) { (void)hipFree(m.d_photons); m.d_photons = nullptr; m.n = 0; }
-    std::vector<DevPhoton> dev;
-    try { dev.resize((size_t)n + 1); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
-    memset(dev.data(), 0, sizeof(DevPhoton));
+    std::vector<DevPhotonPos> dev;                  // [n+1] positions, then [n+1] powers (same record size)
+    try { dev.resize(2 * ((size_t)n + 1)); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
+    memset(dev.data(), 0, sizeof(DevPhotonPos));
+    DevPhotonPow* pw = reinterpret_cast<DevPhotonPow*>(dev.data() + (size_t)n + 1);
+    memset(pw, 0, sizeof(DevPhotonPow));
     for (int64_t i = 1; i <= n; ++i) {
         const rt_photon& p = heap[i];
-        DevPhoton& d = dev[(size_t)i];
-        memcpy(d.pos, p.position, 12); memcpy(d.power, p.power, 12);
+        DevPhotonPos& d = dev[(size_t)i];
+        memcpy(d.pos, p.position, 12); memcpy(pw[i].power, p.power, 12);
         d.packed = ((uint32_t)p.plane & 3u) | ((uint32_t)p.theta << 8) | ((uint32_t)p.phi << 16);
-        d.pad = 0;
+        pw[i].pad = 0;
     }
-    hipError_t e = hipMalloc((void**)&m.d_photons, dev.size() * sizeof(DevPhoton));
-    if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(photon map %zu B): %s", dev.size() * sizeof(DevPhoton), hipGetErrorString(e));
-    HIPCHK(hipMemcpy(m.d_photons, dev.data(), dev.size() * sizeof(DevPhoton), hipMemcpyHostToDevice), "copy photon map");
+    hipError_t e = hipMalloc((void**)&m.d_photons, dev.size() * sizeof(DevPhotonPos));
+    if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(photon map %zu B): %s", dev.size() * sizeof(DevPhotonPos), hipGetErrorString(e));
+    HIPCHK(hipMemcpy(m.d_photons, dev.data(), dev.size() * sizeof(DevPhotonPos), hipMemcpyHostToDevice), "copy photon map");
     m.n = n;
     m.half = n / 2 - 1;                       // photon.cpp:168
     return ensure_tables(s);

@@ -64,13 +64,13 @@ struct DevLight {           // 64 B
     float dir2[3]; float size2;
 };
 
-struct DevPhoton {          // 32 B, heap order (1-based; slot 0 unused)
-    float pos[3];
-    uint32_t packed;        // plane (bits 0..1) | theta<<8 | phi<<16
-    float power[3];
-    uint32_t pad;
-};
-static_assert(sizeof(DevPhoton) == 32, "DevPhoton must be 32 bytes");
+// Photon map in HBM: two arrays in the reference's 1-based heap order (slot 0 unused), back to back in one
+// allocation.  A tree visit reads only DevPhotonPos (16 B); the power array is touched once per found photon.
+// 10 M photons: 160 MB of positions (fits the 256 MB Infinity Cache) + 160 MB of powers.
+struct DevPhotonPos { float pos[3]; uint32_t packed; };    // packed: plane (bits 0..1) | theta<<8 | phi<<16
+struct DevPhotonPow { float power[3]; uint32_t pad; };
+static_assert(sizeof(DevPhotonPos) == 16 && sizeof(DevPhotonPow) == 16, "photon records must be 16 bytes");
+typedef DevPhotonPos DevPhoton;   // base pointer of the allocation: [n+1] DevPhotonPos then [n+1] DevPhotonPow
 
 struct DevSceneView {       // passed by value to kernels
     const DevNode* nodes; int32_t nnodes;      // reference order (= layout 7: right child first everywhere)
