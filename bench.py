@@ -184,9 +184,117 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
                             queries=n_queries, k=k, radius=radius),
                 ms_per_step=ms, heap_build_host_s=build_s,
                 roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=None, visits_per_lookup=visits, bytes_per_lookup=bytes_per),
+                              traffic=_traffic("knn_10m.k_photon_knn"), visits_per_lookup=visits, bytes_per_lookup=bytes_per),
                 cpu_baseline=dict(value=ns / cpu_s, unit="lookups/s", cores=1, kind="port",
                                   sample=f"{ns} of the same queries, oracle LocatePhoton"))
+
+
+def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500):
+    """BASELINE configuration 3's scene: the synthetic 1 M-triangle mesh (raytracer_amd/synth.py) at 3840x2160,
+    primary + shadow rays.  Here the KD-tree (224 k nodes, 2.4 M leaf records, 126 MB per octant-ordered copy set)
+    no longer fits any cache, so the HBM roofline of the closest-hit kernel means something."""
+    from raytracer_amd import abi, host, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    t0 = time.perf_counter()
+    sd = synth.mesh_scene(nu, nv)
+    gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gs = host.Scene(sd, device=local_rank)
+    build_s = time.perf_counter() - t0
+    inf = gs.info()
+    cam = host.camera_for(sd, BASE_RES)
+    params = host.default_params("hw4", primary_only=1)
+    frame = torch.zeros(BASE_RES[0] * BASE_RES[1] * 3, dtype=torch.uint8, device="cuda")
+    st = abi.rt_stats()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tot = dict(ms=0.0, closest=0.0, anyh=0.0, rays=0, prim=0)
+    for i in range(steps + 1):
+        abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(), None, C.byref(st), sp))
+        if i:
+            tot["ms"] += st.kernel_ms; tot["closest"] += st.trace_closest_ms; tot["anyh"] += st.trace_any_ms
+            tot["rays"] += st.rays_primary + st.rays_shadow; tot["prim"] += st.rays_primary
+    alg = algorithmic_bytes_per_ray(gs, cam, params, sp)
+    avg_ms = tot["closest"] / steps
+    gbs = alg["bytes_per_ray"] * (tot["prim"] / steps) / (avg_ms * 1e-3) / 1e9
+    traffic = _traffic("mesh_1m.k_trace_closest")
+    # CPU baseline: the oracle port on a strided sample of the same frame (the reference binary would need the scene as
+    # 130 MB of text and minutes of KD build printing every node)
+    o = ol.OracleScene(sd)
+    res = (240, 135)
+    t0 = time.perf_counter()
+    o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *res), host.default_params("hw4", primary_only=1))
+    cpu_s = time.perf_counter() - t0
+    crays = o.counters().rays_traced
+    o.close(); gs.close()
+    return dict(metric="Mrays/s (KD-tree traversal, primary + shadow rays)", value=tot["rays"] / (tot["ms"] * 1e-3) / 1e6,
+                unit="Mrays/s", ms_per_step=tot["ms"] / steps,
+                config=dict(workload=f"synthetic displaced-sphere mesh, {sd.nprim} triangles + floor, {BASE_RES[0]}x{BASE_RES[1]}, "
+                                     "primary + shadow rays", kd_nodes=int(inf.flat_nodes), leaf_records=int(inf.leaf_refs),
+                            scene_device_mb=inf.device_bytes / 1e6, scene_gen_s=gen_s, kd_build_upload_s=build_s),
+                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
+                              kernel="k_trace_closest", avg_launch_ms=avg_ms, rays_per_launch=tot["prim"] / steps,
+                              bytes_per_ray=alg["bytes_per_ray"], box_tests_per_ray=alg["box_tests_per_ray"],
+                              tri_tests_per_ray=alg["tri_tests_per_ray"], any_hit_ms_per_step=tot["anyh"] / steps,
+                              note="algorithmic bytes count every lane's node / triangle reads; the kernel fetches a record once "
+                                   "per wave on the scalar path, so achieved can exceed what HBM itself delivers"),
+                cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", cores=1, kind="port",
+                                  sample=f"the same scene at {res[0]}x{res[1]}, primary + shadow rays, oracle port", seconds=cpu_s))
+
+
+def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_000, res=(192, 192)):
+    """BASELINE configuration 4's pipeline end to end on the bundled Final scene: GPU emission of both maps, host balance,
+    then the photon-mapping frame (caustic kNN r=0.1 + 50 gather rays with global kNN r=1.0, k=100, 400 light samples)."""
+    from raytracer_amd import abi, host, scene
+    from raytracer_amd import dist as rdist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    sd = scene.parse_scene_file(os.path.join(ROOT, "tests", "golden", "final_input.txt"), flavour="final")
+    gs = host.Scene(sd, device=local_rank)
+    t0 = time.perf_counter()
+    maps = rdist.build_photon_maps(gs, torch, (n_global, n_caustic), seed=1)
+    maps_s = time.perf_counter() - t0
+    cam = host.camera_for(sd, res)
+    p = host.default_params("final", aa_taps=1)
+    frame = torch.zeros(res[0] * res[1] * 3, dtype=torch.uint8, device="cuda")
+    st = abi.rt_stats()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), sp))
+    rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract + st.rays_gather
+    # CPU baseline: the oracle's restatement of the same frame at 10x10 pixels, same maps
+    o = ol.OracleScene(sd)
+    cres = (10, 10)
+    t0 = time.perf_counter()
+    o.render_photon(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), p, maps[0]["heap"], maps[1]["heap"])
+    cpu_s = time.perf_counter() - t0
+    c = o.counters()
+    crays = c.rays_primary + c.rays_shadow + c.rays_reflect + c.rays_refract + c.rays_gather
+    o.close(); gs.close()
+    return dict(metric="photon-mapping frame: Mrays/s and kNN radiance lookups/s", value=rays / (st.kernel_ms * 1e-3) / 1e6,
+                unit="Mrays/s", lookups_per_s=st.knn_lookups / (st.kernel_ms * 1e-3), ms_per_frame=st.kernel_ms,
+                config=dict(workload=f"bundled Final scene, {res[0]}x{res[1]}, 1 AA tap, 50 gather rays, 20x20 light samples, k=100",
+                            photons_global=n_global, photons_caustic=n_caustic, emissions_global=maps[0]["emissions"],
+                            emissions_caustic=maps[1]["emissions"], maps_emit_balance_upload_s=maps_s),
+                rays=dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract,
+                          gather=st.rays_gather), knn_lookups=st.knn_lookups,
+                cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", lookups_per_s=c.knn_lookups / cpu_s, cores=1,
+                                  kind="port", sample=f"the same frame at {cres[0]}x{cres[1]}, same photon maps, oracle port",
+                                  seconds=cpu_s))
+
+
+def _traffic(key):
+    """HBM bytes per launch from the committed PMC summary (tools/prof_pmc.sh -> profiles/traffic_r01.json)"""
+    tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if not os.path.exists(tf):
+        return None
+    try:
+        d = json.load(open(tf))
+        for part in key.split("."):
+            d = d[part]
+        return d.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def main():
@@ -195,7 +303,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--no-knn", action="store_true", help="skip the secondary lines (kNN, 1M-triangle mesh, photon frame)")
+    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,photon_frame")
     ap.add_argument("--knn-photons", type=int, default=10_000_000)
     ap.add_argument("--knn-queries", type=int, default=1920 * 1080)
     ap.add_argument("--cpu-sample", type=str, default="960x540")
@@ -331,13 +440,7 @@ def main():
         rays_per_launch = tot["closest_rays"] / launches
         avg_ms = tot["closest_ms"] / launches
         gbs = alg["bytes_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("k_trace_closest", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = _traffic("monkey_4k.k_trace_closest")
         out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": "k_trace_closest", "avg_launch_ms": avg_ms,
                            "rays_per_launch": rays_per_launch, "bytes_per_ray": alg["bytes_per_ray"],
@@ -351,10 +454,17 @@ def main():
             w, h = (int(x) for x in args.cpu_sample.split("x"))
             out["cpu_baseline"] = cpu_baseline(sd, (w, h))
         if not args.no_knn and n == 1:
-            try:
-                out["secondary"] = knn_secondary(gs, torch, args.knn_photons, args.knn_queries)
-            except abi.RtError as e:
-                out["secondary"] = {"error": str(e)}
+            sec = {}
+            for name, fn in (("knn", lambda: knn_secondary(gs, torch, args.knn_photons, args.knn_queries)),
+                             ("mesh_1m", lambda: mesh_secondary(torch, local_rank)),
+                             ("photon_frame", lambda: photon_frame_secondary(torch, local_rank))):
+                if args.only_secondary and name not in args.only_secondary.split(","):
+                    continue
+                try:
+                    sec[name] = fn()
+                except Exception as e:           # a secondary line must never take the headline down with it
+                    sec[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["secondary"] = sec
     if n > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -221,6 +221,18 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
 #define RT_OPT_TRAVERSAL    1
 #define RT_TRAVERSAL_STRICT 0
 #define RT_TRAVERSAL_FAST   1
+/* kNN algorithm of rt_photon_irradiance*, rt_photon_knn_set and the photon renderer:
+ *   RT_KNN_STRICT  (default) LocatePhoton's array/heap code statement by statement: np.index in the reference's
+ *                  order, irradiance summed in that order (bit-identical to the reference)
+ *   RT_KNN_FAST    (k <= 112) same visits, same accept test, candidates in registers of 16 cooperating
+ *                  lanes: the same SET of photons; queries where a tie for the farthest candidate makes the set
+ *                  depend on the heap's history are redone strictly; irradiance adds the same photons in another
+ *                  order (float association only).  Measured 14 % SLOWER than strict on MI355X (both are bound
+ *                  by vector-instruction issue), so it is an option, not the default.  RT_KNN=strict|fast sets
+ *                  the default of new scenes.                                                                  */
+#define RT_OPT_KNN          2
+#define RT_KNN_STRICT       0
+#define RT_KNN_FAST         1
 int rt_scene_set_option(rt_scene* s, int option, int value);
 
 
@@ -326,6 +338,12 @@ int rt_photon_knn(rt_scene* s, int which, const float* pos3, int64_t q, int k,
 int rt_photon_knn_dev(rt_scene* s, int which, const float* d_pos3, int64_t q, int k,
                       float maxDist, int32_t* d_idx, float* d_dist2,
                       int32_t* d_found, float* d_radius2, void* hip_stream);
+/* The same photons as rt_photon_knn (same found, same radius2), listed in no particular order: what the scene's
+ * kNN option computes (RT_KNN_FAST: the cooperative kernel).  No counterpart in the reference, whose only
+ * consumer of np.index, CalcIrradiance (photon.cpp:418-429), sums over the list.                              */
+int rt_photon_knn_set(rt_scene* s, int which, const float* pos3, int64_t q, int k,
+                      float maxDist, int32_t* idx, float* dist2, int32_t* found,
+                      float* radius2);
 
 /* Replaces PhotonMap::CalcIrradiance in BALANCE_TREE mode (photon.cpp:391-441
  * with GetPhotonDirection :29-36 and the tables :40-50).  rgb: [q][3].         */

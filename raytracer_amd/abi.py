@@ -17,6 +17,7 @@ RT_SCENE_CULLING, RT_SCENE_KD_REFERENCE = 1, 2
 RT_RENDER_WHITTED, RT_RENDER_PHOTON = 0, 1
 RT_PMAP_GLOBAL, RT_PMAP_CAUSTIC = 0, 1
 RT_OPT_TRAVERSAL, RT_TRAVERSAL_STRICT, RT_TRAVERSAL_FAST = 1, 0, 1
+RT_OPT_KNN, RT_KNN_STRICT, RT_KNN_FAST = 2, 0, 1
 
 _f, _i32, _i64, _u8 = C.c_float, C.c_int32, C.c_int64, C.c_uint8
 
@@ -85,7 +86,7 @@ SYMBOLS = [
     "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit", "rt_photonmap_emit_dev",
-    "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_irradiance", "rt_photon_irradiance_dev",
+    "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_knn_set", "rt_photon_irradiance", "rt_photon_irradiance_dev",
     "rt_render", "rt_render_dev", "rt_render_radiance", "rt_generate_primary_dev",
 ]
 
@@ -143,6 +144,7 @@ def load():
         L.rt_photonmap_emit.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64)]
         L.rt_photonmap_emit_dev.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64), vp]
         L.rt_photon_knn.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp]
+        L.rt_photon_knn_set.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp]
         L.rt_photon_knn_dev.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]
         L.rt_photon_irradiance.argtypes = [vp, i32, vp, vp, i64, i32, C.c_float, vp]
         L.rt_photon_irradiance_dev.argtypes = [vp, i32, vp, vp, i64, i32, C.c_float, vp, vp]

@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(64)
 k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
              const float* __restrict__ nrm3, int64_t q, int k, float maxDist, int mode,
              int32_t* __restrict__ out_idx, float* __restrict__ out_d2, int32_t* __restrict__ out_found,
-             float* __restrict__ out_r2, float* __restrict__ out_rgb, const float* __restrict__ tables, int xcd_map) {
+             float* __restrict__ out_r2, float* __restrict__ out_rgb, const float* __restrict__ tables, int xcd_map,
+             const uint8_t* __restrict__ only) {
     extern __shared__ float lds[];
     KnnLds L;
     L.hd = lds;
@@ -150,6 +151,7 @@ k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const fl
     const unsigned lb = xcd_map ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
     const int64_t i = (int64_t)lb * KNN_QL + t;
     if (t >= KNN_QL || i >= q) return;
+    if (only && !only[i]) return;                                  // redo pass: only the queries the fast kernel flagged
     const float qx = pos3[3 * i], qy = pos3[3 * i + 1], qz = pos3[3 * i + 2];
     float r2 = maxDist * maxDist;                                  // np.dist2[0], photon.cpp:405
     int found;
@@ -186,6 +188,165 @@ k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const fl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FAST kNN: 16 lanes per query, 4 queries per wave, no LDS.
+//
+// The strict kernel above replays the reference's array/heap code statement by statement, which pins the ORDER of
+// np.index; its price is a per-query heap in LDS (808 B at k = 100), latency-bound sift loops and 4 useful lanes per
+// wave.  What the reference's result depends on is only the SET: LocatePhoton visits the nodes in an order the
+// candidate list does not influence except through its current maximum, accepts a candidate iff dist2 < that
+// maximum, and evicts the maximum.  So here the k candidates of a query live in the registers of its 16 lanes
+// (slot s -> lane s % 16, register s / 16), the maximum is a 16-lane reduction, and the walk (same visits, same
+// order, same accept test, incl. the reference's quirk that the first candidate after the list is full evicts the
+// farthest even when it is farther) leaves the same set -- unless two candidates tie for the maximum when one must
+// go: which one the reference's heap drops depends on its history, so such a query is flagged and redone by the
+// strict kernel.  The irradiance sum adds the same photons in slot order instead of heap order (float association).
+#define COOP_L 16
+
+template <int S>
+struct CoopSet { float d[S]; int ix[S]; };
+
+__device__ __forceinline__ float group_max16(float v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, COOP_L));
+    return v;
+}
+__device__ __forceinline__ float group_sum16(float v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, COOP_L);
+    return v;
+}
+__device__ __forceinline__ int group_sum16i(int v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, COOP_L);
+    return v;
+}
+
+template <int S>
+__device__ __forceinline__ void coop_consider(CoopSet<S>& c, int l16, int k, int& found, float& r2, bool& ambiguous,
+                                              int index, float dist2) {
+    if (!(dist2 < r2)) return;
+    if (found < k) {
+        const int slot = found;
+        if (l16 == (slot & 15)) {
+#pragma unroll
+            for (int r = 0; r < S; ++r) if (r == (slot >> 4)) { c.d[r] = dist2; c.ix[r] = index; }
+        }
+        ++found;
+        return;
+    }
+    // evict the maximum (slots < k are all valid here)
+    float lm = -1.0f; int lr = 0, neq = 0;
+#pragma unroll
+    for (int r = 0; r < S; ++r) if (r * 16 + l16 < k && c.d[r] > lm) { lm = c.d[r]; lr = r; }
+    const float M = group_max16(lm);
+#pragma unroll
+    for (int r = 0; r < S; ++r) neq += (r * 16 + l16 < k && c.d[r] == M) ? 1 : 0;
+    if (group_sum16i(neq) > 1) ambiguous = true;
+    const unsigned long long owners = __ballot(lm == M) >> (threadIdx.x & 48);       // this group's 16 bits
+    const int owner = __builtin_ctz((unsigned)(owners & 0xffffu));
+    if (l16 == owner) {
+#pragma unroll
+        for (int r = 0; r < S; ++r) if (r == lr) { c.d[r] = dist2; c.ix[r] = index; }
+    }
+    lm = -1.0f;
+#pragma unroll
+    for (int r = 0; r < S; ++r) if (r * 16 + l16 < k && c.d[r] > lm) lm = c.d[r];
+    r2 = group_max16(lm);                                                           // np.dist2[0] = np.dist2[1]
+}
+
+// mode 1: irradiance rgb.   mode 2: the candidate SET (idx/dist2 in slot order, found, radius2).
+template <int S>
+__global__ void __launch_bounds__(64)
+k_photon_knn_coop(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
+                  const float* __restrict__ nrm3, int64_t q, int k, float maxDist, int mode,
+                  int32_t* __restrict__ out_idx, float* __restrict__ out_d2, int32_t* __restrict__ out_found,
+                  float* __restrict__ out_r2, float* __restrict__ out_rgb, const float* __restrict__ tables,
+                  uint8_t* __restrict__ flagged) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (i >= q) return;                                   // whole 16-lane groups leave together
+    const float qx = pos3[3 * i], qy = pos3[3 * i + 1], qz = pos3[3 * i + 2];
+    CoopSet<S> c;
+#pragma unroll
+    for (int r = 0; r < S; ++r) { c.d[r] = 0.f; c.ix[r] = 0; }
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};       // per-level stash: level v -> lane v % 16, register v / 16
+    float r2 = maxDist * maxDist;
+    int found = 0;
+    bool ambiguous = false, done = n < 1;
+    unsigned idx = 1;
+    const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
+    while (!done) {                                       // uniform within a 16-lane group
+        const float4 rec = *reinterpret_cast<const float4*>(ph + idx);
+        float d1 = rec.x - qx;
+        float dist2 = d1 * d1;
+        d1 = rec.y - qy; dist2 += d1 * d1;
+        d1 = rec.z - qz; dist2 += d1 * d1;
+        if (idx < uhalf) {
+            const int plane = __float_as_int(rec.w) & 3;
+            const float pp = plane == 0 ? rec.x : (plane == 1 ? rec.y : rec.z);
+            const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
+            const float dist1 = qp - pp;
+            const int lvl = 31 - __builtin_clz(idx);
+            if (l16 == (lvl & 15)) {
+                if (lvl >> 4) { st1[1] = dist1; st2[1] = dist2; } else { st1[0] = dist1; st2[0] = dist2; }
+            }
+            idx = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
+            continue;
+        }
+        int cidx = (int)idx;
+        float cd2 = dist2;
+        for (;;) {
+            coop_consider<S>(c, l16, k, found, r2, ambiguous, cidx, cd2);
+            if (idx == 1) { done = true; break; }
+            const unsigned child = idx;
+            idx >>= 1;
+            const int lvl = 31 - __builtin_clz(idx);
+            const float dist1 = __shfl((lvl >> 4) ? st1[1] : st1[0], lvl & 15, COOP_L);
+            const unsigned near = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
+            if (child == near && dist1 * dist1 < r2) { idx = near ^ 1u; break; }
+            cidx = (int)idx; cd2 = __shfl((lvl >> 4) ? st2[1] : st2[0], lvl & 15, COOP_L);
+        }
+    }
+    if (flagged && l16 == 0) flagged[i] = ambiguous ? 1 : 0;
+    if (mode == 2) {
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            const int slot = r * 16 + l16;
+            if (slot < k) {
+                out_idx[i * k + slot] = slot < found ? c.ix[r] : -1;
+                out_d2[i * k + slot] = slot < found ? c.d[r] : 0.0f;
+            }
+        }
+        if (l16 == 0) { out_found[i] = found; if (out_r2) out_r2[i] = r2; }
+        return;
+    }
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (found >= 8) {                                              // literal 8, photon.cpp:411
+        const float nx = nrm3[3 * i], ny = nrm3[3 * i + 1], nz = nrm3[3 * i + 2];
+        const float* cosT = tables; const float* sinT = tables + 256;
+        const float* cosP = tables + 512; const float* sinP = tables + 768;
+        const DevPhotonPow* pw = reinterpret_cast<const DevPhotonPow*>(ph + (n + 1));
+#pragma unroll
+        for (int rr = 0; rr < S; ++rr) {
+            if (rr * 16 + l16 < found) {
+                const int pi = c.ix[rr];
+                const unsigned pk = ph[pi].packed;
+                const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
+                const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
+                if ((dx * nx + dy * ny + dz * nz) < 0.0f) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(pw + pi);
+                    r += w4.x; g += w4.y; b += w4.z;
+                }
+            }
+        }
+        r = group_sum16(r); g = group_sum16(g); b = group_sum16(b);
+        const float tmp = (float)(((double)1.0f / 3.141592) / (double)r2);           // (1.0f/PI)/(np.dist2[0])
+        r *= tmp; g *= tmp; b *= tmp;
+    }
+    if (l16 == 0) { out_rgb[3 * i] = r; out_rgb[3 * i + 1] = g; out_rgb[3 * i + 2] = b; }
+}
+
 static int knn_ql() {
     static int ql = 0;
     if (!ql) {
@@ -200,7 +361,7 @@ size_t rtk_knn_lds_bytes(int k) { return (size_t)(2 * (k + 1) + 2 * KNN_LEVELS) 
 template <int QL>
 static hipError_t launch_knn(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
                              int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
-                             float* d_r2, float* d_rgb, const float* d_tables, hipStream_t st) {
+                             float* d_r2, float* d_rgb, const float* d_tables, const uint8_t* only, hipStream_t st) {
     const size_t lds = (size_t)(2 * (k + 1) + 2 * KNN_LEVELS) * QL * 4;
     if (lds > 64 * 1024) {   // per current device; cheap enough to repeat
         hipError_t e = hipFuncSetAttribute((const void*)k_photon_knn<QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -208,7 +369,7 @@ static hipError_t launch_knn(const DevPhoton* ph, int64_t n, int64_t half, const
     }
     const unsigned grid = (unsigned)((((q + QL - 1) / QL) + 7) / 8) * 8;
     hipLaunchKernelGGL(k_photon_knn<QL>, dim3(grid), dim3(64), lds, st, ph, n, half, d_pos3, d_nrm3, q,
-                       k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, getenv("RT_KNN_XCD") ? atoi(getenv("RT_KNN_XCD")) : 0);
+                       k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, getenv("RT_KNN_XCD") ? atoi(getenv("RT_KNN_XCD")) : 0, only);
     return hipGetLastError();
 }
 
@@ -216,7 +377,7 @@ hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const fl
                           int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
                           float* d_r2, float* d_rgb, const float* d_tables, hipStream_t st) {
     if (q <= 0) return hipSuccess;
-#define KNN_ARGS ph, n, half, d_pos3, d_nrm3, q, k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, st
+#define KNN_ARGS ph, n, half, d_pos3, d_nrm3, q, k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, nullptr, st
     switch (knn_ql()) {
         case 2: return launch_knn<2>(KNN_ARGS);
         case 4: return launch_knn<4>(KNN_ARGS);
@@ -227,4 +388,24 @@ hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const fl
         default: return launch_knn<4>(KNN_ARGS);
     }
 #undef KNN_ARGS
+}
+
+// Fast path: cooperative kernel (modes 1 / 2), then the strict kernel redoes the flagged queries.  d_flagged: q bytes.
+hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
+                               int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
+                               float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st) {
+    if (q <= 0) return hipSuccess;
+    if (k > 112 || !d_flagged) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((q + 3) / 4);
+    if (k <= 48)
+        hipLaunchKernelGGL(k_photon_knn_coop<3>, dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, mode, d_idx,
+                           d_d2, d_found, d_r2, d_rgb, d_tables, d_flagged);
+    else
+        hipLaunchKernelGGL(k_photon_knn_coop<7>, dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, mode, d_idx,
+                           d_d2, d_found, d_r2, d_rgb, d_tables, d_flagged);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // redo of the (rare) flagged queries with the reference's exact list code; mode 2 -> mode 0 writes the ordered list
+    return launch_knn<4>(ph, n, half, d_pos3, d_nrm3, q, k, maxDist, mode == 2 ? 0 : 1, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables,
+                         d_flagged, st);
 }

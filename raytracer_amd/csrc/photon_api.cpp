@@ -12,7 +12,7 @@
 
 namespace {
 
-enum { S_Q_POS = 0, S_Q_NRM = 1, S_Q_IDX = 2, S_Q_D2 = 3, S_Q_FOUND = 4, S_Q_R2 = 5, S_Q_RGB = 6 };
+enum { S_Q_POS = 0, S_Q_NRM = 1, S_Q_IDX = 2, S_Q_D2 = 3, S_Q_FOUND = 4, S_Q_R2 = 5, S_Q_RGB = 6, S_Q_FLAG = 11 };
 const int KNN_K_MAX = 287;       // (2(k+1)+64)*256 B of LDS must fit 160 KiB
 
 // InitDirectionTable, photon.cpp:40-50 (PI = 3.141592, parameter.h:6)
@@ -126,6 +126,35 @@ int rt_photon_knn(rt_scene* s, int which, const float* pos3, int64_t q, int k, f
     return RT_OK;
 }
 
+int rt_photon_knn_set(rt_scene* s, int which, const float* pos3, int64_t q, int k, float maxDist, int32_t* idx, float* dist2,
+                  int32_t* found, float* radius2) {
+    RTCHK(check_map(s, which, k, "rt_photon_knn_set"));
+    if (q < 0 || (q > 0 && (!pos3 || !idx || !dist2 || !found))) return rt_fail(RT_E_INVALID, "rt_photon_knn_set: bad argument");
+    if (q == 0) return RT_OK;
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    void *dp, *di, *dd, *df, *dr;
+    RTCHK(s->scratch(S_Q_POS, (size_t)q * 12, &dp));
+    RTCHK(s->scratch(S_Q_IDX, (size_t)q * k * 4, &di));
+    RTCHK(s->scratch(S_Q_D2, (size_t)q * k * 4, &dd));
+    RTCHK(s->scratch(S_Q_FOUND, (size_t)q * 4, &df));
+    RTCHK(s->scratch(S_Q_R2, (size_t)q * 4, &dr));
+    HIPCHK(hipMemcpy(dp, pos3, (size_t)q * 12, hipMemcpyHostToDevice), "copy queries");
+    const PhotonMapDev& m = s->pmap[which];
+    if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
+        void* fl; RTCHK(s->scratch(S_Q_FLAG, (size_t)q, &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, (const float*)dp, nullptr, q, k, maxDist, 2, (int32_t*)di, (float*)dd,
+                                   (int32_t*)df, (float*)dr, nullptr, s->d_dir_tables, (uint8_t*)fl, nullptr), "k_photon_knn_coop");
+    } else
+    HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, (const float*)dp, nullptr, q, k, maxDist, 0, (int32_t*)di, (float*)dd,
+                          (int32_t*)df, (float*)dr, nullptr, s->d_dir_tables, nullptr), "k_photon_knn");
+    HIPCHK(hipMemcpy(idx, di, (size_t)q * k * 4, hipMemcpyDeviceToHost), "copy idx");
+    HIPCHK(hipMemcpy(dist2, dd, (size_t)q * k * 4, hipMemcpyDeviceToHost), "copy dist2");
+    HIPCHK(hipMemcpy(found, df, (size_t)q * 4, hipMemcpyDeviceToHost), "copy found");
+    if (radius2) HIPCHK(hipMemcpy(radius2, dr, (size_t)q * 4, hipMemcpyDeviceToHost), "copy radius2");
+    return RT_OK;
+}
+
 int rt_photon_irradiance_dev(rt_scene* s, int which, const float* d_pos3, const float* d_nrm3, int64_t q, int k,
                              float maxDist, float* d_rgb, void* stream) {
     RTCHK(check_map(s, which, k, "rt_photon_irradiance_dev"));
@@ -133,6 +162,12 @@ int rt_photon_irradiance_dev(rt_scene* s, int which, const float* d_pos3, const 
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
     const PhotonMapDev& m = s->pmap[which];
+    if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
+        void* fl; RTCHK(s->scratch(S_Q_FLAG, (size_t)q, &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, d_pos3, d_nrm3, q, k, maxDist, 1, nullptr, nullptr, nullptr, nullptr,
+                                   d_rgb, s->d_dir_tables, (uint8_t*)fl, (hipStream_t)stream), "k_photon_knn_coop");
+        return RT_OK;
+    }
     HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, d_pos3, d_nrm3, q, k, maxDist, 1, nullptr, nullptr, nullptr, nullptr,
                           d_rgb, s->d_dir_tables, (hipStream_t)stream), "k_photon_knn");
     return RT_OK;
@@ -152,6 +187,11 @@ int rt_photon_irradiance(rt_scene* s, int which, const float* pos3, const float*
     HIPCHK(hipMemcpy(dp, pos3, (size_t)q * 12, hipMemcpyHostToDevice), "copy queries");
     HIPCHK(hipMemcpy(dn, nrm3, (size_t)q * 12, hipMemcpyHostToDevice), "copy normals");
     const PhotonMapDev& m = s->pmap[which];
+    if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
+        void* fl; RTCHK(s->scratch(S_Q_FLAG, (size_t)q, &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, (const float*)dp, (const float*)dn, q, k, maxDist, 1, nullptr, nullptr,
+                                   nullptr, nullptr, (float*)dc, s->d_dir_tables, (uint8_t*)fl, nullptr), "k_photon_knn_coop");
+    } else
     HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, (const float*)dp, (const float*)dn, q, k, maxDist, 1, nullptr, nullptr,
                           nullptr, nullptr, (float*)dc, s->d_dir_tables, nullptr), "k_photon_knn");
     HIPCHK(hipMemcpy(rgb, dc, (size_t)q * 12, hipMemcpyDeviceToHost), "copy rgb");

@@ -21,9 +21,10 @@ enum {
     P_TILES = 3, P_PIXMAP, P_WHITE, P_HITANY, P_ACCUM, P_CTR,
     P_QA_RAYS, P_QA_SID, P_QA_W, P_QA_CODE, P_QB_RAYS, P_QB_SID, P_QB_W, P_QB_CODE,
     P_HITS, P_FLAGS, P_NRM, P_NRML, P_QPOS, P_CAUSTIC, P_OCC, P_CONTRIB, P_BSUMS,
-    P_G_SLOTS   // one more slot of gather state is packed behind this one (see GatherBuf)
+    P_G_SLOTS,  // the gather queues and their per-ray arrays, carved from one slot (Arena)
+    P_KNN_FLAG  // queries the fast kNN kernel hands to the strict one
 };
-static_assert(P_G_SLOTS + 1 <= RT_NSCRATCH, "not enough scratch slots");
+static_assert(P_KNN_FLAG + 1 <= RT_NSCRATCH, "not enough scratch slots");
 
 struct Arena {   // bump allocator over one scratch slot
     char* base = nullptr; size_t cap = 0, off = 0;
@@ -38,6 +39,12 @@ struct Arena {   // bump allocator over one scratch slot
 int knn(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st) {
     const PhotonMapDev& m = s->pmap[which];
     if (!m.d_photons || m.n < 1) { HIPCHK(hipMemsetAsync(rgb, 0, (size_t)q * 12, st), "memset irradiance"); return RT_OK; }
+    if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
+        void* fl; RTCHK(s->scratch(P_KNN_FLAG, (size_t)q, &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, pos, nrm, q, k, radius, 1, nullptr, nullptr, nullptr, nullptr, rgb,
+                                   s->d_dir_tables, (uint8_t*)fl, st), "k_photon_knn_coop");
+        return RT_OK;
+    }
     HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, pos, nrm, q, k, radius, 1, nullptr, nullptr, nullptr, nullptr, rgb,
                           s->d_dir_tables, st), "k_photon_knn");
     return RT_OK;

@@ -131,6 +131,10 @@ class Scene:
         abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_TRAVERSAL,
                                              abi.RT_TRAVERSAL_STRICT if mode == "strict" else abi.RT_TRAVERSAL_FAST))
 
+    def set_knn(self, mode):
+        """"strict" (the reference's list order, bit-identical irradiance) or "fast" (same photon set; default)."""
+        abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_KNN, abi.RT_KNN_STRICT if mode == "strict" else abi.RT_KNN_FAST))
+
     def info(self):
         i = abi.rt_scene_info()
         abi.check(self.L.rt_scene_info_get(self.h, C.byref(i)))
@@ -217,6 +221,16 @@ class Scene:
         found = np.zeros(q, np.int32); r2 = np.zeros(q, np.float32)
         abi.check(self.L.rt_photon_knn(self.h, which, pos.ctypes.data, q, k, float(max_dist), idx.ctypes.data,
                                        d2.ctypes.data, found.ctypes.data, r2.ctypes.data))
+        return idx, d2, found, r2
+
+    def photon_knn_set(self, which, pos, k, max_dist):
+        """the photons of photon_knn in unspecified order (the scene's kNN option decides the kernel)"""
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        q = pos.shape[0]
+        idx = np.zeros((q, k), np.int32); d2 = np.zeros((q, k), np.float32)
+        found = np.zeros(q, np.int32); r2 = np.zeros(q, np.float32)
+        abi.check(self.L.rt_photon_knn_set(self.h, which, pos.ctypes.data, q, k, float(max_dist), idx.ctypes.data,
+                                           d2.ctypes.data, found.ctypes.data, r2.ctypes.data))
         return idx, d2, found, r2
 
     def photon_irradiance(self, which, pos, nrm, k, max_dist):

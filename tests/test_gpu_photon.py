@@ -1,7 +1,9 @@
 """GPU parity: photon-map kNN / irradiance (HIP, LDS max-heaps) against the reference's
 fixture (LocatePhoton / CalcIrradiance called through oracle/_ref) and the CPU oracle.
 Bar: bit-exact index lists (in the reference's np.index order), squared distances, radius
-and irradiance."""
+and -- with the strict kNN option -- irradiance; with the fast option (default) the index SETS, found and
+radius are bit-exact and the irradiance, which adds the same photons in another order, is within 1e-5
+relative (float association only)."""
 import ctypes as C
 import os
 
@@ -19,12 +21,32 @@ def _load(name):
         return {k: np.ascontiguousarray(z[k]) for k in z.files}
 
 
-@pytest.fixture(scope="module")
-def gscene():
+@pytest.fixture(scope="module", params=["fast", "strict"])
+def gscene(request):
     sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
     s = host.Scene(sd)
+    s.set_knn(request.param)
+    s.knn_mode = request.param
     yield s
     s.close()
+
+
+def _irr_equal(s, got, want):
+    if s.knn_mode == "strict":
+        return got.tobytes() == want.tobytes()
+    return bool(np.allclose(got, want, rtol=1e-5, atol=1e-12))
+
+
+def _sets_equal(idx, d2, found, oi, od, of):
+    """the same photons with the same squared distances, whatever the order"""
+    if not np.array_equal(found, of):
+        return False
+    a = np.sort(np.where(idx >= 0, idx, np.iinfo(np.int32).max), axis=1)
+    b = np.sort(np.where(oi >= 0, oi, np.iinfo(np.int32).max), axis=1)
+    if not np.array_equal(a, b):
+        return False
+    oa, ob = np.argsort(idx, axis=1, kind="stable"), np.argsort(oi, axis=1, kind="stable")
+    return np.take_along_axis(d2, oa, 1).tobytes() == np.take_along_axis(od, ob, 1).tobytes()
 
 
 def _oracle_knn(heap, qp, k, maxd):
@@ -54,7 +76,9 @@ def test_knn_and_irradiance_vs_reference_fixture(gscene, tag):
     assert np.array_equal(found, g[f"found_{tag}"]) and np.array_equal(idx, g[f"idx_{tag}"])
     assert d2.tobytes() == g[f"d2_{tag}"].tobytes() and r2.tobytes() == g[f"r2_{tag}"].tobytes()
     rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, g["qpos"], g["qnrm"], k, maxd)
-    assert rgb.tobytes() == g[f"rgb_{tag}"].tobytes()
+    assert _irr_equal(gscene, rgb, g[f"rgb_{tag}"])
+    si, sd2, sf, sr = gscene.photon_knn_set(abi.RT_PMAP_GLOBAL, g["qpos"], k, maxd)
+    assert _sets_equal(si, sd2, sf, g[f"idx_{tag}"], g[f"d2_{tag}"], g[f"found_{tag}"]) and sr.tobytes() == g[f"r2_{tag}"].tobytes()
 
 
 def test_build_from_unbalanced_equals_reference_heap(gscene):
@@ -93,7 +117,10 @@ def test_large_map_many_k_vs_oracle(gscene):
         assert np.array_equal(gf, of) and np.array_equal(gi, oi), (k, maxd)
         assert gd.tobytes() == od.tobytes() and gr.tobytes() == orr.tobytes()
         rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, k, maxd)
-        assert rgb.tobytes() == _oracle_irr(heap, qp, qn, k, maxd).tobytes(), (k, maxd)
+        assert _irr_equal(gscene, rgb, _oracle_irr(heap, qp, qn, k, maxd)), (k, maxd)
+        si, sd2, sf, sr = gscene.photon_knn_set(abi.RT_PMAP_GLOBAL, qp, k, maxd)
+        oi, od, of, orr = _oracle_knn(heap, qp, k, maxd)
+        assert _sets_equal(si, sd2, sf, oi, od, of) and sr.tobytes() == orr.tobytes(), (k, maxd)
 
 
 def test_tiny_and_empty_maps(gscene):
@@ -140,4 +167,28 @@ def test_dev_entry_points(gscene):
                                          dr.data_ptr(), st))
     abi.check(gscene.L.rt_photon_irradiance_dev(gscene.h, 0, dp.data_ptr(), dn.data_ptr(), q, k, 1.0, dc.data_ptr(), st))
     torch.cuda.synchronize()
-    assert np.array_equal(di.cpu().numpy(), g["idx_r1"]) and dc.cpu().numpy().tobytes() == g["rgb_r1"].tobytes()
+    assert np.array_equal(di.cpu().numpy(), g["idx_r1"]) and _irr_equal(gscene, dc.cpu().numpy(), g["rgb_r1"])
+
+
+def test_lattice_of_ties_goes_through_the_strict_redo(gscene):
+    """photons on a regular lattice (and duplicated): most queries meet candidates that tie for the farthest place, where
+    the surviving set depends on the reference heap's history -- the fast kernel must hand those to the strict one."""
+    n1 = 14
+    ax = (np.arange(n1, dtype=np.float32) / np.float32(n1) - np.float32(0.5))
+    pts = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    pts = np.concatenate([pts, pts[::3]])                              # exact duplicates too
+    n = pts.shape[0]
+    a = np.zeros(n + 1, abi.photon_dtype)
+    a["position"][1:] = pts; a["power"][1:] = np.float32(1.0 / n)
+    rng = np.random.default_rng(4)
+    a["phi"][1:] = rng.integers(0, 256, n); a["theta"][1:] = rng.integers(0, 256, n)
+    heap = gscene.photonmap_build(abi.RT_PMAP_GLOBAL, a)
+    qp = np.concatenate([pts[rng.choice(n1 ** 3, 300)],                # queries ON lattice points: symmetric ties
+                         rng.uniform(-0.5, 0.4, (300, 3)).astype(np.float32)])
+    qn = rng.normal(size=qp.shape).astype(np.float32)
+    for k, maxd in ((20, 0.3), (100, 0.5), (7, 2.0)):
+        oi, od, of, orr = _oracle_knn(heap, qp, k, maxd)
+        si, sd2, sf, sr = gscene.photon_knn_set(abi.RT_PMAP_GLOBAL, qp, k, maxd)
+        assert _sets_equal(si, sd2, sf, oi, od, of) and sr.tobytes() == orr.tobytes(), (k, maxd)
+        rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, k, maxd)
+        assert _irr_equal(gscene, rgb, _oracle_irr(heap, qp, qn, k, maxd)), (k, maxd)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""One workload of bench.py, alone, for rocprofv3 (so a kernel name maps to one workload):
+    python3 tools/prof_target.py monkey_4k | mesh_1m | knn_10m | photon_frame"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch            # noqa: E402
+import bench            # noqa: E402
+from raytracer_amd import abi, host   # noqa: E402
+
+what = sys.argv[1]
+if what == "monkey_4k":
+    sd = bench.bench_scene()
+    gs = host.Scene(sd)
+    cam = host.camera_for(sd, bench.BASE_RES)
+    p = host.default_params("hw4", primary_only=1)
+    frame = torch.zeros(bench.BASE_RES[0] * bench.BASE_RES[1] * 3, dtype=torch.uint8, device="cuda")
+    st = abi.rt_stats()
+    for _ in range(5):
+        abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), None))
+    print("monkey_4k closest ms", st.trace_closest_ms)
+elif what == "mesh_1m":
+    r = bench.mesh_secondary(torch, 0, steps=3)
+    print("mesh_1m", r["value"], r["roofline"]["avg_launch_ms"])
+elif what == "knn_10m":
+    gs = host.Scene(bench.bench_scene())
+    r = bench.knn_secondary(gs, torch, 10_000_000, 1920 * 1080, steps=2)
+    print("knn_10m", r["value"], r["ms_per_step"])
+elif what == "photon_frame":
+    r = bench.photon_frame_secondary(torch, 0)
+    print("photon_frame", r["value"], r["lookups_per_s"])
+else:
+    sys.exit("unknown workload")
