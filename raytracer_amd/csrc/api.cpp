@@ -199,6 +199,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.nodes[o], &v.nodes_oct[o]);
     v.nodes = v.nodes_oct[7];
     if (!rc) rc = upload(s, flat.leaf_tris, &v.leaf_tris);
+    if (!rc) rc = upload(s, flat.leaf_groups, &v.leaf_groups);
     if (!rc) rc = upload(s, flat.loose, &v.loose);
     if (!rc) rc = upload(s, flat.prim_normal, &v.prim_normal);
     if (!rc) rc = upload(s, flat.prim_geom, &v.prim_geom);
@@ -388,9 +389,9 @@ extern "C" int64_t rt_host_flat_get(const rt_host_flat* f, int which, void* dst,
             case 2: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].meta; break;
             case 3: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].leaf_first; break;
             case 4: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].leaf_count; break;
-            case 5: ((int32_t*)dst)[i] = h.leaf_tris[(size_t)i].prim; break;
+            case 5: ((int32_t*)dst)[h.leaf_tris[(size_t)i].rank] = h.leaf_tris[(size_t)i].prim; break;   // in visit-rank order
             case 6: ((int32_t*)dst)[i] = h.loose[(size_t)i].prim; break;
-            case 7: memcpy((float*)dst + 9 * i, h.leaf_tris[(size_t)i].v0, 36); break;
+            case 7: memcpy((float*)dst + 9 * (size_t)h.leaf_tris[(size_t)i].rank, h.leaf_tris[(size_t)i].v0, 36); break;
         }
     }
     return rows;

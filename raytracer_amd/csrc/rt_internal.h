@@ -22,7 +22,7 @@ struct DevNode {            // 48 B, fetched wave-uniformly (scalar path)
     float margin;           // relative slack for distance culling of this subtree (fast traversal)
     int32_t leaf_first;     // leaf: first record in leaf_tris (== reference visit rank of its first triangle)
     int32_t leaf_count;
-    int32_t pad;
+    int32_t group_first;    // leaf: first DevLeafGroup; the leaf's records are cut into ceil(leaf_count / 8) groups
 };
 static_assert(sizeof(DevNode) == 48, "DevNode must be 48 bytes");
 
@@ -36,9 +36,23 @@ struct DevLeafTri {         // 48 B
     float e2[3];            // vertices[2]-vertices[0]   (hw4.cpp:178)
     int32_t prim;           // scene-file index
     int32_t flags;          // bit0: material refract > 0.1 (final.cpp:999)
-    int32_t pad;
+    int32_t rank;           // position of this reference in the reference's visit order (tie-break key)
 };
 static_assert(sizeof(DevLeafTri) == 48, "DevLeafTri must be 48 bytes");
+
+// Inside a leaf the records are sorted along a Morton curve and cut into groups of <= RT_GROUP consecutive
+// records; a group carries the bounding box of its triangles.  The fast traversal skips a group whose (inflated)
+// box a ray misses or that lies beyond its best hit -- a culling layer under the reference's tree.
+#define RT_GROUP 8
+struct DevLeafGroup {       // 64 B
+    float lo[3]; float hi[3];
+    float gm;               // max |edge1|*|edge2| over the group's triangles
+    float area2_min;        // min |edge1 x edge2| over its non-degenerate triangles
+    float axis[3];          // unit mean normal; every triangle normal is within the cone (cos_t, sin_t) around +-axis
+    float cos_t, sin_t;
+    float pad[3];
+};
+static_assert(sizeof(DevLeafGroup) == 64, "DevLeafGroup must be 64 bytes");
 
 #define RT_PF_SKIP_SHADOW 1   // refract > 0.1
 #define RT_PF_SPHERE      2
@@ -77,6 +91,7 @@ struct DevSceneView {       // passed by value to kernels
     const DevNode* nodes_oct[8];               // layout o: at a node split on axis a the child on the side the
                                                // ray comes from is first (bit a of o set = direction negative)
     const DevLeafTri* leaf_tris;
+    const DevLeafGroup* leaf_groups;
     const DevLoose* loose; int32_t nloose;
     const float* prim_normal;   // [nprim][3] fixed-point normal (triangles)
     const int32_t* prim_material;
@@ -98,6 +113,7 @@ struct DevSceneView {       // passed by value to kernels
 struct HostFlatScene {
     std::vector<DevNode> nodes[8];             // nodes[7] is the reference order
     std::vector<DevLeafTri> leaf_tris;
+    std::vector<DevLeafGroup> leaf_groups;
     std::vector<DevLoose> loose;
     std::vector<float> prim_normal;
     std::vector<float> prim_geom;

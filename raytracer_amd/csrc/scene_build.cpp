@@ -5,6 +5,7 @@
 // uploaded to HBM by api.cpp.
 #include "rt_internal.h"
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -27,7 +28,7 @@ struct BuildNode {
     bool leaf = false;
     float model_scale = 2.0f;        // KDNode ctor default (hw4.h:203); only roots get another value
     // filled while flattening in reference order, reused by the other seven layouts
-    int32_t leaf_first = 0;
+    int32_t leaf_first = 0, group_first = 0;
     float margin = 0.f;
 };
 
@@ -122,17 +123,78 @@ struct Flattener {
         float margin = 0.f;
         if (n.leaf) {
             n.leaf_first = (int32_t)out->leaf_tris.size();
-            for (int32_t id : n.prims) {
-                DevLeafTri t{};
-                float a[9]; fill_tri(a, d->prims[id].f);
-                memcpy(t.v0, a, 12); memcpy(t.e1, a + 3, 12); memcpy(t.e2, a + 6, 12);
-                t.prim = id;
-                t.flags = ((double)d->materials[d->prim_material[id]].refract > 0.1) ? RT_PF_SKIP_SHADOW : 0;
-                out->leaf_tris.push_back(t);
-                // |edge1|*|edge2| bounds the cancellation in det and in the t numerator
-                const float l1 = std::sqrt(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]);
-                const float l2 = std::sqrt(a[6] * a[6] + a[7] * a[7] + a[8] * a[8]);
-                margin = std::max(margin, l1 * l2);
+            n.group_first = (int32_t)out->leaf_groups.size();
+            // records of this leaf, in the reference's list order (rank), then sorted along a Morton curve
+            struct Ref { uint32_t code; int32_t k; };
+            std::vector<Ref> refs(n.prims.size());
+            for (size_t k = 0; k < n.prims.size(); ++k) {
+                const float* f = d->prims[n.prims[k]].f;
+                uint32_t code = 0;
+                for (int ax = 0; ax < 3; ++ax) {
+                    const float c = (f[ax] + f[3 + ax] + f[6 + ax]) * (1.0f / 3.0f);
+                    const float lo = n.center[ax] - n.extend[ax] * 0.5f, ext = n.extend[ax] > 0.f ? n.extend[ax] : 1.f;
+                    float u = (c - lo) / ext; u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
+                    uint32_t q = (uint32_t)(u * 1023.0f);
+                    q = (q | (q << 16)) & 0x030000FF; q = (q | (q << 8)) & 0x0300F00F;
+                    q = (q | (q << 4)) & 0x030C30C3; q = (q | (q << 2)) & 0x09249249;
+                    code |= q << ax;
+                }
+                refs[k] = Ref{code, (int32_t)k};
+            }
+            std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.code < b.code; });
+            for (size_t g0 = 0; g0 < refs.size(); g0 += RT_GROUP) {
+                DevLeafGroup g{};
+                for (int k = 0; k < 3; ++k) { g.lo[k] = 1e30f; g.hi[k] = -1e30f; }
+                float gm = 0.f;
+                double amin = 1e300, ax[3] = {0, 0, 0};
+                std::vector<std::array<double, 3>> nrm;
+                for (size_t j = g0; j < std::min(refs.size(), g0 + RT_GROUP); ++j) {
+                    const int32_t id = n.prims[(size_t)refs[j].k];
+                    const float* f = d->prims[id].f;
+                    DevLeafTri t{};
+                    float a[9]; fill_tri(a, f);
+                    memcpy(t.v0, a, 12); memcpy(t.e1, a + 3, 12); memcpy(t.e2, a + 6, 12);
+                    t.prim = id;
+                    t.flags = ((double)d->materials[d->prim_material[id]].refract > 0.1) ? RT_PF_SKIP_SHADOW : 0;
+                    t.rank = n.leaf_first + refs[j].k;
+                    out->leaf_tris.push_back(t);
+                    for (int v = 0; v < 3; ++v)
+                        for (int k = 0; k < 3; ++k) { g.lo[k] = std::min(g.lo[k], f[3 * v + k]); g.hi[k] = std::max(g.hi[k], f[3 * v + k]); }
+                    // |edge1|*|edge2| bounds the cancellation in det and in the t / u / v numerators
+                    const float l1 = std::sqrt(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]);
+                    const float l2 = std::sqrt(a[6] * a[6] + a[7] * a[7] + a[8] * a[8]);
+                    gm = std::max(gm, l1 * l2);
+                    // normal cone: det = dir . (edge2 x edge1), so |det| >= |edge1 x edge2| * |dir . n|
+                    const double cx = (double)a[4] * a[8] - (double)a[5] * a[7], cy = (double)a[5] * a[6] - (double)a[3] * a[8],
+                                 cz = (double)a[3] * a[7] - (double)a[4] * a[6];
+                    const double ar = std::sqrt(cx * cx + cy * cy + cz * cz);
+                    if (ar > 0) {
+                        amin = std::min(amin, ar);
+                        std::array<double, 3> u = {cx / ar, cy / ar, cz / ar};
+                        // normals are taken up to sign: align with the first one
+                        if (!nrm.empty() && u[0] * nrm[0][0] + u[1] * nrm[0][1] + u[2] * nrm[0][2] < 0) { u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; }
+                        nrm.push_back(u); ax[0] += u[0]; ax[1] += u[1]; ax[2] += u[2];
+                    }
+                }
+                g.gm = gm;
+                const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+                double cmin = 0.0;
+                if (al > 1e-12 && !nrm.empty()) {
+                    cmin = 1.0;
+                    for (const auto& u : nrm) cmin = std::min(cmin, (u[0] * ax[0] + u[1] * ax[1] + u[2] * ax[2]) / al);
+                    for (int k = 0; k < 3; ++k) g.axis[k] = (float)(ax[k] / al);
+                }
+                // round the cone outwards: a slightly smaller cosine, a slightly larger sine
+                cmin = std::max(0.0, cmin - 1e-4);
+                g.cos_t = (float)cmin; g.sin_t = (float)std::min(1.0, std::sqrt(std::max(0.0, 1.0 - cmin * cmin)) + 1e-4);
+                g.area2_min = nrm.empty() ? 0.f : (float)(amin * (1.0 - 1e-5));
+                // the cone costs ~12 vector ops per test: only worth it where the worst-case slack (|det| = 1e-6) is not
+                // already small against the box (typical reach of a ray through the scene: a few units)
+                float ext = 0.f;
+                for (int k = 0; k < 3; ++k) ext = std::max(ext, g.hi[k] - g.lo[k]);
+                g.pad[0] = (2.0f * gm * 4.0f > 0.1f * ext) ? 1.0f : 0.0f;
+                margin = std::max(margin, gm);
+                out->leaf_groups.push_back(g);
             }
         } else {
             emit_reference(*n.right, depth + 1);
@@ -170,7 +232,7 @@ struct Flattener {
         r.margin = 4.0f * n.margin + 1e-4f;
         r.leaf_first = n.leaf ? n.leaf_first : 0;
         r.leaf_count = n.leaf ? (int32_t)n.prims.size() : 0;
-        r.pad = 0;
+        r.group_first = n.leaf ? n.group_first : 0;
     }
 };
 

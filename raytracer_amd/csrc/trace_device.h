@@ -158,9 +158,12 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
                         if (ANY) {
                             if (len < (use_tmax ? tmax : 1e9f) && len >= sc.tol_f) { occluded = true; fail = RT_DEAD; hit = false; }
                         } else {
-                            if (len < best.len && len >= sc.tol_f &&
+                            // the records of a leaf are stored in Morton order, not in the reference's list order:
+                            // an equal len goes to the lower visit rank, which is what the reference's strict < keeps
+                            if ((len < best.len || (len == best.len && t->rank < best.rank)) && len >= sc.tol_f &&
                                 (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
                                 best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                                best.rank = t->rank;
                             }
                         }
                     }
@@ -184,6 +187,7 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
 struct RayAux {
     float rx, ry, rz;      // RN(1/d) per axis
     float dlen;            // |dir|
+    float rlen;            // 1 / |dir|
     bool plain;            // all direction components finite and non-zero, |dir| in [0.5, 2]: fast paths allowed
 };
 
@@ -191,6 +195,7 @@ __device__ __forceinline__ RayAux ray_aux(const Rayf& r) {
     RayAux a;
     a.rx = 1.0f / r.dx; a.ry = 1.0f / r.dy; a.rz = 1.0f / r.dz;
     a.dlen = sqrt_rn(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
+    a.rlen = 1.0f / a.dlen;
     const float big = 1e18f, small = 1e-18f;
     const float ax = __builtin_fabsf(r.dx), ay = __builtin_fabsf(r.dy), az = __builtin_fabsf(r.dz);
     a.plain = (ax > small && ax < big) && (ay > small && ay < big) && (az > small && az < big) &&
@@ -234,6 +239,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
         const int depth = nd.meta & 0xff;
         if (fail >= depth) fail = RT_ALIVE;
         bool hit = false;
+        float leaf_el = 0.f, leaf_xl = 0.f;
         if (COUNT) w->fetch += 1;
         if (fail == RT_ALIVE) {
             float enter, exit;
@@ -242,6 +248,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
             if (hit && aux.plain) {
                 // lengths along the ray of the slab interval, shrunk/grown by the subtree's slack
                 const float el = enter * aux.dlen, xl = exit * aux.dlen;
+                leaf_el = __builtin_fabsf(el); leaf_xl = __builtin_fabsf(xl);
                 const float slack = nd.margin * (__builtin_fabsf(el) + __builtin_fabsf(xl)) + 1e-6f;
                 const float limit = ANY ? far_limit : best.len;
                 if (xl + slack < 0.0f || el - slack > limit) hit = false;   // behind the origin / beyond the best hit
@@ -250,52 +257,89 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
         }
         if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
         if (nd.meta & 0x100) {
-            for (int k = 0; k < nd.leaf_count; ++k) {
-                const int rank = nd.leaf_first + k;
-                const DevLeafTri* __restrict__ t = sc.leaf_tris + rank;            // wave-uniform
-                if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
-                // --- screening with an approximate reciprocal (same dot products as the exact test) ---
-                const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
-                const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
-                const float pvx = r.dy * e2z - r.dz * e2y;
-                const float pvy = r.dz * e2x - r.dx * e2z;
-                const float pvz = r.dx * e2y - r.dy * e2x;
-                const float det = e1x * pvx + e1y * pvy + e1z * pvz;
-                if (COUNT) { w->fetch += 1; if (hit) w->tri += 1; }
-                bool cand = hit && !(__builtin_fabsf(det) < eps_f);
-                const float ri = __builtin_amdgcn_rcpf(det);
-                const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
-                const float du = tx * pvx + ty * pvy + tz * pvz;
-                const float ua = du * ri;
-                cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
-                if (__ballot(cand) == 0ull) continue;
-                const float qx = ty * e1z - tz * e1y;
-                const float qy = tz * e1x - tx * e1z;
-                const float qz = tx * e1y - ty * e1x;
-                const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
-                const float dt = e2x * qx + e2y * qy + e2z * qz;
-                const float va = dv * ri, ta = dt * ri;
-                cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
-                if (__ballot(cand) == 0ull) continue;
-                // --- the reference's exact sequence for the survivors (hw4.cpp:211-230) ---
-                if (cand) {
-                    if (COUNT) w->exact += 1;
-                    const float detInv = 1.0f / det;
-                    const float u = du * detInv;
-                    if (!(u < 0 || u > 1.0f)) {
-                        const float v = dv * detInv;
-                        if (!(v < 0 || u + v > 1.0f)) {
-                            const float tt = dt * detInv;
-                            if (!(tt < 0)) {
-                                const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
-                                const float len = dist_to(r, px, py, pz);
-                                if (ANY) {
-                                    if (len < far_limit && len >= sc.tol_f) { occluded = true; fail = RT_DEAD; hit = false; }
-                                } else {
-                                    if ((len < best.len || (len == best.len && rank < best.rank)) && len >= sc.tol_f &&
-                                        (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
-                                        best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
-                                        best.rank = rank;
+            // lateral slack of this leaf for the lane: how far outside a triangle's true extent a ray may pass and
+            // still be accepted by the reference's rounded u / v tests, per unit of group factor
+            float reach = 0.f;
+            if (hit && aux.plain) {
+                const float diag = (nd.hi[0] - nd.lo[0]) + (nd.hi[1] - nd.lo[1]) + (nd.hi[2] - nd.lo[2]);
+                reach = leaf_el + leaf_xl + 2.0f * diag;
+            }
+            const int ngroups = (nd.leaf_count + RT_GROUP - 1) / RT_GROUP;
+            for (int g = 0; g < ngroups; ++g) {
+                const DevLeafGroup* __restrict__ gp = sc.leaf_groups + (nd.group_first + g);   // wave-uniform
+                bool ghit = hit;
+                if (COUNT) { w->fetch += 1; if (hit) w->box += 1; }
+                if (hit && aux.plain) {
+                    // slack: 4 x the first-order bound 5 eps |e1||e2| (|tvec| + |e|) / |det| on how far outside a triangle
+                    // (and how far off in t) a hit the reference accepts can be.  |det| >= |e1 x e2| |dir . n|, bounded from
+                    // below through the group's normal cone; never below the reference's own cut-off 1e-6 (hw4.cpp:209).
+                    float lat = 2.0f * gp->gm;                                 // |det| >= 1e-6: 1.2e-6 gm / 1e-6, rounded up
+                    if (gp->pad[0] != 0.0f) {                                  // wave-uniform
+                        const float c = __builtin_fabsf(r.dx * gp->axis[0] + r.dy * gp->axis[1] + r.dz * gp->axis[2]) * aux.rlen;
+                        const float cc = __builtin_fminf(c, 1.0f);
+                        const float lb = cc * gp->cos_t - sqrt_rn(1.0f - cc * cc) * gp->sin_t; // cos(angle + cone) <= |dir . n| / |dir|
+                        const float detmin = __builtin_fmaxf(gp->area2_min * lb * aux.dlen * 0.999f, 1e-6f);
+                        lat = 1.2e-6f * gp->gm / detmin;
+                    }
+                    const float sl = (lat + 2e-5f) * reach + 1e-6f;
+                    const float x0 = (gp->lo[0] - sl - r.ox) * aux.rx, x1 = (gp->hi[0] + sl - r.ox) * aux.rx;
+                    const float y0 = (gp->lo[1] - sl - r.oy) * aux.ry, y1 = (gp->hi[1] + sl - r.oy) * aux.ry;
+                    const float z0 = (gp->lo[2] - sl - r.oz) * aux.rz, z1 = (gp->hi[2] + sl - r.oz) * aux.rz;
+                    const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+                    const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+                    const float limit = ANY ? far_limit : best.len;
+                    // the box is already inflated by sl on every side: the interval test needs no further slack
+                    if (ex < en || ex * aux.dlen < 0.0f || en * aux.dlen > limit) ghit = false;
+                }
+                if (__ballot(ghit) == 0ull) continue;
+                const int t0 = nd.leaf_first + g * RT_GROUP;
+                const int t1 = (t0 + RT_GROUP < nd.leaf_first + nd.leaf_count) ? t0 + RT_GROUP : nd.leaf_first + nd.leaf_count;
+                for (int ti = t0; ti < t1; ++ti) {
+                    const DevLeafTri* __restrict__ t = sc.leaf_tris + ti;               // wave-uniform
+                    if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+                    // --- screening with an approximate reciprocal (same dot products as the exact test) ---
+                    const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
+                    const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
+                    const float pvx = r.dy * e2z - r.dz * e2y;
+                    const float pvy = r.dz * e2x - r.dx * e2z;
+                    const float pvz = r.dx * e2y - r.dy * e2x;
+                    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+                    if (COUNT) { w->fetch += 1; if (ghit) w->tri += 1; }
+                    bool cand = ghit && !(__builtin_fabsf(det) < eps_f);
+                    const float ri = __builtin_amdgcn_rcpf(det);
+                    const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
+                    const float du = tx * pvx + ty * pvy + tz * pvz;
+                    const float ua = du * ri;
+                    cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
+                    if (__ballot(cand) == 0ull) continue;
+                    const float qx = ty * e1z - tz * e1y;
+                    const float qy = tz * e1x - tx * e1z;
+                    const float qz = tx * e1y - ty * e1x;
+                    const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
+                    const float dt = e2x * qx + e2y * qy + e2z * qz;
+                    const float va = dv * ri, ta = dt * ri;
+                    cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
+                    if (__ballot(cand) == 0ull) continue;
+                    // --- the reference's exact sequence for the survivors (hw4.cpp:211-230) ---
+                    if (cand) {
+                        if (COUNT) w->exact += 1;
+                        const float detInv = 1.0f / det;
+                        const float u = du * detInv;
+                        if (!(u < 0 || u > 1.0f)) {
+                            const float v = dv * detInv;
+                            if (!(v < 0 || u + v > 1.0f)) {
+                                const float tt = dt * detInv;
+                                if (!(tt < 0)) {
+                                    const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
+                                    const float len = dist_to(r, px, py, pz);
+                                    if (ANY) {
+                                        if (len < far_limit && len >= sc.tol_f) { occluded = true; fail = RT_DEAD; hit = false; ghit = false; }
+                                    } else {
+                                        if ((len < best.len || (len == best.len && t->rank < best.rank)) && len >= sc.tol_f &&
+                                            (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
+                                            best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                                            best.rank = t->rank;
+                                        }
                                     }
                                 }
                             }
