@@ -168,6 +168,15 @@ typedef struct rt_params {
     int32_t count_work;         /* 1: also run the counting traversal on every pass and fill
                                    rt_stats.closest_work / any_work (measurement only, slow) */
     uint64_t seed;              /* counter-based RNG key (build-defined)         */
+    /* distributed ray tracing (RT_RENDER_WHITTED only).  NOT in the reference, which traces one centre sample per
+     * pixel with point lights and mirror reflection: these are the build-defined samplers BASELINE's configuration 3
+     * names.  All zero = the reference's image, bit for bit.                                        */
+    int32_t spp;                /* samples per pixel, jittered inside the pixel; <= 1: one centre sample        */
+    float   lens_radius;        /* depth of field: thin-lens radius, 0 = pinhole                                 */
+    float   focal_distance;     /* distance along the primary ray of the point in focus                         */
+    float   light_radius;       /* soft shadows: every light is a ball of this radius, one sample per shadow ray */
+    float   glossy;             /* glossy reflection: reflected direction + glossy * (random point in unit ball) */
+    int32_t pad_;
 } rt_params;
 
 /* Work counters (the reference keeps checkTime / totalIntersectionCheck,

@@ -491,8 +491,23 @@ void orc_primary_ray(const rt_camera* cam, float px, float py, rt_ray* ray) {
 /* std::max(a,b) = (a<b)?b:a : a NaN first argument is returned as is */
 static inline float maxf_std(float a, float b) { return (a < b) ? b : a; }
 
+/* ---- distributed-ray-tracing samplers: BUILD-DEFINED (the reference traces one centre sample per pixel, point
+ * lights, mirror reflection); restated here from raytracer_amd/csrc/rng_device.h, "parity unpinned". ---------- */
+float orc_rng(uint64_t seed, uint64_t a, uint64_t b, uint64_t c);
+static void drt_ball(uint64_t seed, uint64_t a, uint64_t b, uint64_t c0, float out3[3]) {
+    float u = orc_rng(seed, a, b, c0), v = orc_rng(seed, a, b, c0 + 1);
+    float w = orc_rng(seed, a, b, c0 + 2), w2 = orc_rng(seed, a, b, c0 + 3), w3 = orc_rng(seed, a, b, c0 + 4);
+    w = w < w2 ? w2 : w; w = w < w3 ? w3 : w;
+    float z = 1.0f - 2.0f * u;
+    float rr = 1.0f - z * z;
+    float r = sqrtf(rr < 0.0f ? 0.0f : rr);
+    double phi = 6.283185307179586 * (double)v;
+    out3[0] = w * (r * (float)cos(phi)); out3[1] = w * (r * (float)sin(phi)); out3[2] = w * z;
+}
+
 /* ---- SimpleMeshRayTrace, hw4.cpp:794-955 --------------------------------- */
-typedef struct { orc_scene* s; const rt_camera* cam; const rt_params* p; int hit_any; int32_t first_prim; } rctx;
+typedef struct { orc_scene* s; const rt_camera* cam; const rt_params* p; int hit_any; int32_t first_prim;
+                 int drt; uint64_t key; /* pixel << 16 | sample */ uint32_t code; /* position in the recursion */ } rctx;
 
 static v3 whitted(rctx* c, v3 ori, v3 dir, int depth, float currentNr) {
     orc_scene* s = c->s;
@@ -507,10 +522,16 @@ static v3 whitted(rctx* c, v3 ori, v3 dir, int depth, float currentNr) {
     v3 surf = vload(m->surf);
     v3 normal = get_normal(s, prim, hitPoint);
     if (vdot(normal, dir) > 0) normal = vmuls(normal, -1.0f);
+    const uint32_t code = c->code;
     if (!c->p->primary_only && m->reflect > 0.0001f) {
         float dot = vdot(dir, normal);
         v3 reflected = vsub(dir, vmuls(normal, 2 * dot));
+        if (c->drt && c->p->glossy > 0.f) {
+            float b3[3]; drt_ball(c->p->seed, c->key, code, 8, b3);
+            reflected = vnorm(V(reflected.x + c->p->glossy * b3[0], reflected.y + c->p->glossy * b3[1], reflected.z + c->p->glossy * b3[2]));
+        }
         s->c.rays_reflect++;
+        c->code = (2u * code) & 0xffffu;
         v3 rc = whitted(c, hitPoint, reflected, depth + 1, currentNr);
         colour = vadd(colour, vmuls(rc, m->reflect));
     }
@@ -521,16 +542,23 @@ static v3 whitted(rctx* c, v3 ori, v3 dir, int depth, float currentNr) {
         v3 transmitted = vnorm(vadd(vmuls(dir, n1 / n2), vmuls(normal, cos1 * (n1 / n2) - sqrtf(1 - (sin2 * sin2)))));
         v3 displacePoint = vsub(hitPoint, vmuls(normal, s->refract_bias));
         s->c.rays_refract++;
+        c->code = (2u * code + 1u) & 0xffffu;
         v3 rc = whitted(c, displacePoint, transmitted, depth + 1, n2);
         colour = vadd(colour, vmuls(rc, m->refract));
     }
+    c->code = code;
     v3 ambient = vmuls(vmuls(surf, c->p->ambient_intensity), m->Ka);
     colour = vadd(colour, ambient);
     for (int i = 0; i < s->nlight; i++) {
         v3 lpos = vload(s->lights[i].pos);
         /* IsInShadow, hw4.cpp:957-967 */
         v3 point = vadd(hitPoint, vmuls(normal, s->shadow_bias));
-        v3 rayDir = vnorm(vsub(lpos, point));
+        v3 lsample = lpos;
+        if (c->drt && c->p->light_radius > 0.f) {
+            float b3[3]; drt_ball(c->p->seed, c->key, code, 16 + 8 * (uint64_t)i, b3);
+            lsample = V(lpos.x + c->p->light_radius * b3[0], lpos.y + c->p->light_radius * b3[1], lpos.z + c->p->light_radius * b3[2]);
+        }
+        v3 rayDir = vnorm(vsub(lsample, point));
         s->c.rays_shadow++;
         if (!any_hit(s, point, rayDir, 0, 0.0f)) {
             v3 toLight = vnorm(vsub(lpos, hitPoint));
@@ -559,23 +587,46 @@ static inline uint8_t quant(float c) {
 void orc_render_whitted(orc_scene* s, const rt_camera* cam, const rt_params* p,
                         uint8_t* rgb8, int32_t* hit_ids, float* radiance) {
     rctx c; c.s = s; c.cam = cam; c.p = p;
+    const int spp = p->spp > 1 ? p->spp : 1;
+    c.drt = spp > 1 || p->lens_radius > 0.f || p->light_radius > 0.f || p->glossy > 0.f;
     s->c.average_check = 0;
     for (int x = 0; x < cam->resx; x++) {
         for (int y = 0; y < cam->resy; y++) {
             s->total_check = 0; s->check_time = 0;
-            rt_ray r; orc_primary_ray(cam, (float)x, (float)y, &r);
-            c.hit_any = 0; c.first_prim = -1;
-            s->c.rays_primary++;
-            v3 col = whitted(&c, vload(r.o), vload(r.d), 0, p->start_nr);
-            s->c.average_check += (s->total_check / (double)s->check_time) / (double)(cam->resx * cam->resy);
             size_t px = (size_t)x + (size_t)y * (size_t)cam->resx;
-            if (c.hit_any) {
+            v3 col = V(0, 0, 0);
+            int any = 0; int32_t prim0 = -1;
+            for (int sm = 0; sm < spp; sm++) {
+                /* sample sm of the pixel (build-defined); spp <= 1 and no lens: the reference's centre ray */
+                c.key = ((uint64_t)px << 16) | (uint64_t)sm; c.code = 1;
+                float jx = 0.f, jy = 0.f;
+                if (spp > 1) { jx = orc_rng(p->seed, c.key, 0, 0) - 0.5f; jy = orc_rng(p->seed, c.key, 0, 1) - 0.5f; }
+                rt_ray r; orc_primary_ray(cam, (float)x + jx, (float)y + jy, &r);
+                if (p->lens_radius > 0.f) {
+                    float lr = p->lens_radius * sqrtf(orc_rng(p->seed, c.key, 0, 2));
+                    double phi = 6.283185307179586 * (double)orc_rng(p->seed, c.key, 0, 3);
+                    float cx = lr * (float)cos(phi), cy = lr * (float)sin(phi);
+                    float f[3], o[3];
+                    for (int k = 0; k < 3; k++) f[k] = r.o[k] + p->focal_distance * r.d[k];
+                    for (int k = 0; k < 3; k++) o[k] = (r.o[k] + cx * cam->xaxis[k]) + cy * cam->yaxis[k];
+                    v3 d = vnorm(V(f[0] - o[0], f[1] - o[1], f[2] - o[2]));
+                    vstore(r.o, vload(o)); vstore(r.d, d);
+                }
+                c.hit_any = 0; c.first_prim = -1;
+                s->c.rays_primary++;
+                v3 sc = whitted(&c, vload(r.o), vload(r.d), 0, p->start_nr);
+                if (c.drt) col = vadd(col, vmuls(sc, (float)(1.0 / (double)spp))); else col = sc;
+                any |= c.hit_any;
+                if (sm == 0) prim0 = c.first_prim;
+            }
+            s->c.average_check += (s->total_check / (double)s->check_time) / (double)(cam->resx * cam->resy);
+            if (any) {
                 rgb8[3 * px + 0] = quant(col.x); rgb8[3 * px + 1] = quant(col.y); rgb8[3 * px + 2] = quant(col.z);
             } else {
                 rgb8[3 * px + 0] = (uint8_t)p->background[0]; rgb8[3 * px + 1] = (uint8_t)p->background[1];
                 rgb8[3 * px + 2] = (uint8_t)p->background[2];
             }
-            if (hit_ids) hit_ids[px] = c.first_prim;
+            if (hit_ids) hit_ids[px] = prim0;
             if (radiance) { radiance[3 * px] = col.x; radiance[3 * px + 1] = col.y; radiance[3 * px + 2] = col.z; }
         }
     }

@@ -55,7 +55,8 @@ class rt_params(C.Structure):
                 ("start_nr", _f), ("primary_only", _i32), ("tile_size", _i32), ("tile_rank", _i32),
                 ("tile_nranks", _i32), ("gather_samples", _i32), ("knn_k", _i32), ("knn_radius_global", _f),
                 ("knn_radius_caustic", _f), ("irradiance_max_depth", _i32), ("aa_taps", _i32),
-                ("count_work", _i32), ("seed", C.c_uint64)]
+                ("count_work", _i32), ("seed", C.c_uint64), ("spp", _i32), ("lens_radius", _f), ("focal_distance", _f),
+                ("light_radius", _f), ("glossy", _f), ("pad_", _i32)]
 
 
 class rt_emit_params(C.Structure):

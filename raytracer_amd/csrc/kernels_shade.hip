@@ -17,6 +17,7 @@
 // depend on how the frame is tiled over GPUs.
 #include <hip/hip_runtime.h>
 #include "rt_internal.h"
+#include "rng_device.h"
 
 namespace {
 
@@ -96,7 +97,8 @@ extern "C" __global__ void __launch_bounds__(256)
 k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restrict__ hits,
               const int32_t* __restrict__ pix, int64_t n, int spawn_children, int primary_pass,
               uint8_t* __restrict__ child_flags, rt_ray* __restrict__ srays, int32_t* __restrict__ sactive,
-              int32_t* __restrict__ hit_ids, uint8_t* __restrict__ hit_any, unsigned long long* __restrict__ block_pairs) {
+              int32_t* __restrict__ hit_ids, uint8_t* __restrict__ hit_any, unsigned long long* __restrict__ block_pairs,
+              const uint32_t* __restrict__ code, uint64_t seed, float light_radius) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool inb = i < n;
     const int px = inb ? pix[i] : -1;
@@ -106,8 +108,10 @@ k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __
     if (!inb) return;
     const int L = sc.nlights;
     if (primary_pass && px >= 0) {
-        if (hit_ids) hit_ids[px] = hit ? c.prim : -1;
-        hit_any[px] = hit ? 1 : 0;
+        // with several samples per pixel the id image shows sample 0, and the pixel is "hit" if any sample hit
+        // (k_zero_pixels cleared the flag)
+        if (hit_ids && (!code || (code[i] >> 16) == 0)) hit_ids[px] = hit ? c.prim : -1;
+        if (hit) hit_any[px] = 1;
     }
     uint8_t f0 = 0, f1 = 0;
     if (hit) {
@@ -120,7 +124,13 @@ k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __
         const float bx = c.hx + sc.shadow_bias * c.nx, by = c.hy + sc.shadow_bias * c.ny, bz = c.hz + sc.shadow_bias * c.nz;
         for (int l = 0; l < L; ++l) {
             const DevLight lt = sc.lights[l];
-            float dx = lt.pos[0] - bx, dy = lt.pos[1] - by, dz = lt.pos[2] - bz;
+            float lx = lt.pos[0], ly = lt.pos[1], lz = lt.pos[2];
+            if (light_radius > 0.f && code) {                  // soft shadow: one point of the light ball
+                float b3[3];
+                rt_ball(seed, ((uint64_t)px << 16) | (code[i] >> 16), code[i] & 0xffffu, 16 + 8 * l, b3);
+                lx = lx + light_radius * b3[0]; ly = ly + light_radius * b3[1]; lz = lz + light_radius * b3[2];
+            }
+            float dx = lx - bx, dy = ly - by, dz = lz - bz;
             normalize3(dx, dy, dz);
             float* o = reinterpret_cast<float*>(srays + (i * L + l));
             o[0] = bx; o[1] = by; o[2] = bz; o[3] = dx; o[4] = dy; o[5] = dz;
@@ -239,7 +249,8 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         const int32_t* __restrict__ pix, const float* __restrict__ weight, const float* __restrict__ nr_in,
         const uint8_t* __restrict__ flags, int64_t nflags, const uint32_t* __restrict__ block_offsets,
         rt_ray* __restrict__ orays, int32_t* __restrict__ opix, float* __restrict__ oweight, float* __restrict__ onr,
-        unsigned long long* __restrict__ counters) {
+        unsigned long long* __restrict__ counters, const uint32_t* __restrict__ code, uint32_t* __restrict__ ocode,
+        uint64_t seed, float glossy) {
     __shared__ uint32_t wsum[SCAN_BLOCK / 64];
     __shared__ unsigned int kinds[2];
     if (threadIdx.x < 2) kinds[threadIdx.x] = 0;
@@ -271,7 +282,14 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
             const float dot = c.dx * c.nx + c.dy * c.ny + c.dz * c.nz;
             const float k2 = 2 * dot;                                  // reflected = dir - 2*dot*normal
             o[0] = c.hx; o[1] = c.hy; o[2] = c.hz;
-            o[3] = c.dx - k2 * c.nx; o[4] = c.dy - k2 * c.ny; o[5] = c.dz - k2 * c.nz;
+            float rx = c.dx - k2 * c.nx, ry = c.dy - k2 * c.ny, rz = c.dz - k2 * c.nz;
+            if (glossy > 0.f && code) {                        // glossy lobe
+                float b3[3];
+                rt_ball(seed, ((uint64_t)pix[i] << 16) | (code[i] >> 16), code[i] & 0xffffu, 8, b3);
+                rx = rx + glossy * b3[0]; ry = ry + glossy * b3[1]; rz = rz + glossy * b3[2];
+                normalize3(rx, ry, rz);
+            }
+            o[3] = rx; o[4] = ry; o[5] = rz;
             oweight[pos] = w * m.reflect; onr[pos] = nr_in ? nr_in[i] : 1.0f;
             ++nrefl;
         } else {
@@ -288,6 +306,7 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
             ++nrefr;
         }
         opix[pos] = pix[i];
+        if (ocode) ocode[pos] = (code[i] & 0xffff0000u) | ((2u * (code[i] & 0xffffu) + (unsigned)(slot & 1)) & 0xffffu);
         ++pos;
     }
     if (nrefl) atomicAdd(&kinds[0], (unsigned)nrefl);
@@ -329,11 +348,12 @@ k_copy_radiance(const int32_t* __restrict__ pix0, int64_t n, const float* __rest
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-k_zero_pixels(const int32_t* __restrict__ pix0, int64_t n, float* __restrict__ accum) {
+k_zero_pixels(const int32_t* __restrict__ pix0, int64_t n, float* __restrict__ accum, uint8_t* __restrict__ hit_any) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = pix0[i];
     if (p < 0) return;
+    hit_any[p] = 0;
     accum[3 * (size_t)p] = 0.f; accum[3 * (size_t)p + 1] = 0.f; accum[3 * (size_t)p + 2] = 0.f;
 }
 
@@ -343,12 +363,12 @@ static inline unsigned gridf(int64_t n, int b) { return (unsigned)((n + b - 1) /
 hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
                            int spawn_children, int primary_pass, uint8_t* child_flags, rt_ray* srays, int32_t* sactive,
                            int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, unsigned int* block_pairs,
-                           hipStream_t st) {
+                           const uint32_t* code, uint64_t seed, float light_radius, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const unsigned nb = gridf(n, 256);
     hipLaunchKernelGGL(k_shade_flags, dim3(nb), dim3(256), 0, st, sc, rays, hits, pix, n, spawn_children,
                        primary_pass, child_flags, srays, sactive, hit_ids, hit_any,
-                       reinterpret_cast<unsigned long long*>(block_pairs));
+                       reinterpret_cast<unsigned long long*>(block_pairs), code, seed, light_radius);
     hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, block_pairs, (int64_t)nb, counters);
     return hipGetLastError();
 }
@@ -382,13 +402,14 @@ hipError_t rtk_scan_flags(const uint8_t* flags, int64_t n, uint32_t* block_sums,
 hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
                                 const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
-                                float* onr, unsigned long long* counters, hipStream_t st) {
+                                float* onr, unsigned long long* counters, const uint32_t* code, uint32_t* ocode,
+                                uint64_t seed, float glossy, hipStream_t st) {
     if (nflags <= 0) return hipSuccess;
     const int64_t nb = rtk_scan_blocks_needed(nflags);
     hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, nflags, block_sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, nb, d_total);
     hipLaunchKernelGGL(k_spawn, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, sc, rays, hits, pix, weight, nr_in, flags,
-                       nflags, block_sums, orays, opix, oweight, onr, counters);
+                       nflags, block_sums, orays, opix, oweight, onr, counters, code, ocode, seed, glossy);
     return hipGetLastError();
 }
 
@@ -405,8 +426,8 @@ hipError_t rtk_copy_radiance(const int32_t* pix0, int64_t n, const float* accum,
     return hipGetLastError();
 }
 
-hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, hipStream_t st) {
+hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, uint8_t* hit_any, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_zero_pixels, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum);
+    hipLaunchKernelGGL(k_zero_pixels, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum, hit_any);
     return hipGetLastError();
 }

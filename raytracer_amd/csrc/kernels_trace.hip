@@ -21,6 +21,7 @@
 //
 // Compile with -ffp-contract=off and correctly rounded f32 divide / sqrt.
 #include "trace_device.h"
+#include "rng_device.h"
 
 // ---------------------------------------------------------------------------
 // active: optional per-ray int32 (ray skipped when < 0), used by the renderer
@@ -128,6 +129,49 @@ k_generate_tiled(rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntile
     primary_ray(cam, (float)x + ox, (float)y + oy, o);
 }
 
+// Distributed ray tracing (build-defined): spp jittered samples per pixel, thin lens.  Ray index
+// i = (micro-tile slot * 64 + lane) * spp + s, so the samples of a pixel are contiguous (one run for k_accumulate)
+// and a wave still covers a compact patch of pixels.  pixlist[slot*64+lane] = the pixel (or -1), for zero/finalize.
+extern "C" __global__ void __launch_bounds__(256)
+k_generate_drt(rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntiles, int spp, uint64_t seed,
+               float lens_radius, float focal_distance, rt_ray* __restrict__ rays, int32_t* __restrict__ pix,
+               float* __restrict__ w, uint32_t* __restrict__ code, int32_t* __restrict__ pixlist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntiles * 64 * spp) return;
+    const int64_t slot = i / spp;
+    const int sidx = (int)(i - slot * spp);
+    const int lane = (int)(slot & 63);
+    const int t = tiles ? tiles[slot >> 6] : (int)(slot >> 6);
+    const int tw = (cam.resx + 7) >> 3;
+    const int x = (t % tw) * 8 + (lane & 7), y = (t / tw) * 8 + (lane >> 3);
+    float* o = reinterpret_cast<float*>(rays + i);
+    w[i] = (float)(1.0 / (double)spp);
+    code[i] = ((uint32_t)sidx << 16) | 1u;
+    if (x >= cam.resx || y >= cam.resy) {
+        pix[i] = -1; if (sidx == 0) pixlist[slot] = -1;
+        o[0] = o[1] = o[2] = o[3] = o[4] = 0.f; o[5] = 1.f;
+        return;
+    }
+    const int p = x + y * cam.resx;
+    pix[i] = p; if (sidx == 0) pixlist[slot] = p;
+    const uint64_t key = ((uint64_t)p << 16) | (uint64_t)sidx;
+    float jx = 0.f, jy = 0.f;
+    if (spp > 1) { jx = rt_rng(seed, key, 0, 0) - 0.5f; jy = rt_rng(seed, key, 0, 1) - 0.5f; }
+    primary_ray(cam, (float)x + jx, (float)y + jy, o);
+    if (lens_radius > 0.f) {
+        const float lr = lens_radius * sqrt_rn(rt_rng(seed, key, 0, 2));
+        const double phi = RT_TWO_PI_D * (double)rt_rng(seed, key, 0, 3);
+        const float cx = lr * (float)cos(phi), cy = lr * (float)sin(phi);
+        const float fx = o[0] + focal_distance * o[3], fy = o[1] + focal_distance * o[4], fz = o[2] + focal_distance * o[5];
+        o[0] = (o[0] + cx * cam.xaxis[0]) + cy * cam.yaxis[0];
+        o[1] = (o[1] + cx * cam.xaxis[1]) + cy * cam.yaxis[1];
+        o[2] = (o[2] + cx * cam.xaxis[2]) + cy * cam.yaxis[2];
+        float dx = fx - o[0], dy = fy - o[1], dz = fz - o[2];
+        normalize3(dx, dy, dz);
+        o[3] = dx; o[4] = dy; o[5] = dz;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host launchers (declared in rt_internal.h)
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
@@ -166,5 +210,14 @@ hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int6
     if (ntiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_generate_tiled, dim3(grid_for(ntiles * 64, 256)), dim3(256), 0, st, cam, d_tiles, ntiles, ox,
                        oy, d_rays, d_pix);
+    return hipGetLastError();
+}
+
+hipError_t rtk_generate_drt(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, int spp, uint64_t seed,
+                            float lens_radius, float focal_distance, rt_ray* d_rays, int32_t* d_pix, float* d_w,
+                            uint32_t* d_code, int32_t* d_pixlist, hipStream_t st) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_generate_drt, dim3(grid_for(ntiles * 64 * spp, 256)), dim3(256), 0, st, cam, d_tiles, ntiles, spp,
+                       seed, lens_radius, focal_distance, d_rays, d_pix, d_w, d_code, d_pixlist);
     return hipGetLastError();
 }

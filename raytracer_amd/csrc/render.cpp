@@ -11,9 +11,9 @@ namespace {
 
 enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
-    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK
+    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE
 };
-static_assert(S_WORK < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_QB_CODE < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -54,7 +54,12 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     std::vector<int32_t> tiles;
     rank_microtiles(*cam, *p, tiles);
     const int64_t ntiles = (int64_t)tiles.size();
-    const int64_t n0 = ntiles * 64;
+    // distributed ray tracing: any of the build-defined samplers switches the sample bookkeeping on
+    const int spp = p->spp > 1 ? p->spp : 1;
+    const bool drt = spp > 1 || p->lens_radius > 0.f || p->light_radius > 0.f || p->glossy > 0.f;
+    if (spp > 4096) return rt_fail(RT_E_LIMIT, "rt_render: spp %d > 4096", spp);
+    const int64_t nslots = ntiles * 64;
+    const int64_t n0 = nslots * spp;
     const int L = s->view.nlights;
     const bool whole = (p->tile_size <= 0 || p->tile_nranks <= 1);
 
@@ -88,13 +93,25 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     };
     if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
 
-    HIPCHK(rtk_generate_tiled(*cam, (const int32_t*)d_tiles, ntiles, 0.f, 0.f, (rt_ray*)rays0, (int32_t*)pix0, st), "k_generate_tiled");
-    HIPCHK(rtk_zero_pixels((const int32_t*)pix0, n0, (float*)accum, st), "k_zero_pixels");
+    const int32_t* pixlist = (const int32_t*)pix0;      // one entry per pixel slot of this rank (zero / finalize)
+    const float* q_w = nullptr;          // NULL = weight 1
+    const uint32_t* q_code = nullptr;    // NULL = no sample bookkeeping (the reference's single centre sample)
+    if (drt) {
+        void *w0, *code0, *pl;
+        RTCHK(s->scratch(S_W0, (size_t)n0 * 4, &w0));
+        RTCHK(s->scratch(S_CODE0, (size_t)n0 * 4, &code0));
+        RTCHK(s->scratch(S_PIXLIST, (size_t)nslots * 4, &pl));
+        HIPCHK(rtk_generate_drt(*cam, (const int32_t*)d_tiles, ntiles, spp, p->seed, p->lens_radius, p->focal_distance,
+                                (rt_ray*)rays0, (int32_t*)pix0, (float*)w0, (uint32_t*)code0, (int32_t*)pl, st), "k_generate_drt");
+        pixlist = (const int32_t*)pl; q_w = (const float*)w0; q_code = (const uint32_t*)code0;
+    } else {
+        HIPCHK(rtk_generate_tiled(*cam, (const int32_t*)d_tiles, ntiles, 0.f, 0.f, (rt_ray*)rays0, (int32_t*)pix0, st), "k_generate_tiled");
+    }
+    HIPCHK(rtk_zero_pixels(pixlist, nslots, (float*)accum, (uint8_t*)hitany, st), "k_zero_pixels");
 
     // pass state
     const rt_ray* q_rays = (const rt_ray*)rays0;
     const int32_t* q_pix = (const int32_t*)pix0;
-    const float* q_w = nullptr;          // NULL = weight 1
     const float* q_nr = nullptr;         // NULL = start_nr ... handled below
     int64_t n = n0;
     int64_t passes = 0;
@@ -118,7 +135,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
-                               (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, st), "k_shade_flags");
+                               (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, q_code, p->seed, p->light_radius, st), "k_shade_flags");
         RTCHK(mark());
         if (L > 0)
             HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, s->fast, (uint8_t*)occ, st), "k_trace_any");
@@ -148,17 +165,20 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             HIPCHK(hipMemcpyAsync(tmp, nrfill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st), "copy nr");
             nr_in = (const float*)tmp;
         }
+        void* ocode = nullptr;
+        if (drt) RTCHK(s->scratch(toA ? S_QA_CODE : S_QB_CODE, (size_t)n * 2 * 4, &ocode));
         HIPCHK(rtk_compact_children(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, nr_in, (const uint8_t*)flags, 2 * n,
                                     (uint32_t*)bsums, d_total, (rt_ray*)orays, (int32_t*)opix, (float*)ow, (float*)onr,
-                                    d_ctr, st), "compact children");
+                                    d_ctr, q_code, (uint32_t*)ocode, p->seed, p->glossy, st), "compact children");
         uint32_t total = 0;
         HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st), "read child count");
         HIPCHK(hipStreamSynchronize(st), "sync");
         q_rays = (const rt_ray*)orays; q_pix = (const int32_t*)opix; q_w = (const float*)ow; q_nr = (const float*)onr;
+        q_code = (const uint32_t*)ocode;
         n = (int64_t)total;
     }
-    HIPCHK(rtk_finalize((const int32_t*)pix0, n0, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8, st), "k_finalize");
-    if (s->d_radiance_out) HIPCHK(rtk_copy_radiance((const int32_t*)pix0, n0, (const float*)accum, s->d_radiance_out, st), "k_copy_radiance");
+    HIPCHK(rtk_finalize(pixlist, nslots, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8, st), "k_finalize");
+    if (s->d_radiance_out) HIPCHK(rtk_copy_radiance(pixlist, nslots, (const float*)accum, s->d_radiance_out, st), "k_copy_radiance");
     if (stats) {
         HIPCHK(hipEventRecord(ev1, st), "event");
         unsigned long long h[8], hw[8] = {};

@@ -20,3 +20,21 @@ __host__ __device__ inline float rt_rng(uint64_t seed, uint64_t a, uint64_t b, u
     x = rt_mix64(x ^ (c * 0x165667B19E3779F9ull));
     return (float)(x >> 40) * (1.0f / 16777216.0f);
 }
+
+// ---- distributed-ray-tracing samplers (build-defined; restated in oracle/rt_oracle.c) ----
+// key a = pixel << 16 | sample;  b = position in the recursion (root 1, reflect 2c, refract 2c+1; 0 = camera);
+// c = dimension: camera 0,1 pixel jitter, 2,3 lens;  hit 8..12 glossy ball, 16+8l..20+8l ball of light l.
+#define RT_TWO_PI_D 6.283185307179586
+
+// uniform point in the unit ball from 5 draws: direction from (u, v), radius = max of three uniforms (cdf r^3)
+__device__ inline void rt_ball(uint64_t seed, uint64_t a, uint64_t b, uint64_t c0, float* out3) {
+    const float u = rt_rng(seed, a, b, c0), v = rt_rng(seed, a, b, c0 + 1);
+    float w = rt_rng(seed, a, b, c0 + 2);
+    const float w2 = rt_rng(seed, a, b, c0 + 3), w3 = rt_rng(seed, a, b, c0 + 4);
+    w = w < w2 ? w2 : w; w = w < w3 ? w3 : w;
+    const float z = 1.0f - 2.0f * u;
+    const float rr = 1.0f - z * z;
+    const float r = __builtin_sqrtf(rr < 0.0f ? 0.0f : rr);
+    const double phi = RT_TWO_PI_D * (double)v;
+    out3[0] = w * (r * (float)cos(phi)); out3[1] = w * (r * (float)sin(phi)); out3[2] = w * z;
+}

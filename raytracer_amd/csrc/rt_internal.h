@@ -141,6 +141,9 @@ hipError_t rtk_trace_work(const DevSceneView& sc, const rt_ray* d_rays, const in
                           int64_t n, float eps_f, int fast, int any, unsigned long long* d_out4, hipStream_t st);
 hipError_t rtk_generate_linear(const rt_camera& cam, int64_t first, int64_t n, float ox, float oy, rt_ray* d_rays,
                                hipStream_t st);
+hipError_t rtk_generate_drt(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, int spp, uint64_t seed,
+                            float lens_radius, float focal_distance, rt_ray* d_rays, int32_t* d_pix, float* d_w,
+                            uint32_t* d_code, int32_t* d_pixlist, hipStream_t st);
 hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float ox, float oy,
                               rt_ray* d_rays, int32_t* d_pix, hipStream_t st);
 
@@ -148,6 +151,7 @@ hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int6
 hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
                            int spawn_children, int primary_pass, uint8_t* child_flags, rt_ray* srays, int32_t* sactive,
                            int32_t* hit_ids, uint8_t* hit_any, unsigned long long* counters, unsigned int* block_pairs,
+                           const uint32_t* code, uint64_t seed, float light_radius,
                            hipStream_t st);   // block_pairs: scratch, 2 x ceil(n/256) uint32
 hipError_t rtk_shade_lights(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
                             const float* weight, int64_t n, const uint8_t* occluded, float ambient, const float eye[3],
@@ -157,11 +161,12 @@ int64_t rtk_scan_blocks_needed(int64_t nflags);
 hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix,
                                 const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
-                                float* onr, unsigned long long* counters, hipStream_t st);
+                                float* onr, unsigned long long* counters, const uint32_t* code, uint32_t* ocode,
+                                uint64_t seed, float glossy, hipStream_t st);
 hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
                         uint8_t* rgb8, hipStream_t st);
 hipError_t rtk_copy_radiance(const int32_t* pix0, int64_t n, const float* accum, float* out, hipStream_t st);
-hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, hipStream_t st);
+hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, uint8_t* hit_any, hipStream_t st);
 
 hipError_t rtk_scan_flags(const uint8_t* flags, int64_t n, uint32_t* block_sums, uint32_t* d_total, hipStream_t st);
 

@@ -67,6 +67,7 @@ def default_params(flavour="hw4", **kw):
     p.gather_samples = 50; p.knn_k = 100; p.knn_radius_global = 1.0; p.knn_radius_caustic = 0.1
     p.irradiance_max_depth = 3; p.aa_taps = 0 if flavour == "hw4" else 6
     p.seed = 1
+    p.spp = 0; p.lens_radius = 0.0; p.focal_distance = 0.0; p.light_radius = 0.0; p.glossy = 0.0
     for k, v in kw.items():
         setattr(p, k, v)
     return p
