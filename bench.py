@@ -242,6 +242,42 @@ def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500):
                                   sample=f"the same scene at {res[0]}x{res[1]}, primary + shadow rays, oracle port", seconds=cpu_s))
 
 
+def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
+    """BASELINE configuration 3: distributed ray tracing at 64 spp (jittered pixel samples, thin lens, ball light =
+    soft shadows, glossy reflection) on the synthetic 1 M-triangle scene.  The samplers are build-defined (the reference
+    has none); every ray type is counted."""
+    from raytracer_amd import abi, host, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    sd = synth.mesh_scene(nu, nv, reflect=0.3)
+    gs = host.Scene(sd, device=local_rank)
+    cam = host.camera_for(sd, res)
+    kw = dict(spp=spp, lens_radius=0.01, focal_distance=1.3, light_radius=0.5, glossy=0.05, seed=3)
+    p = host.default_params("hw4", **kw)
+    frame = torch.zeros(res[0] * res[1] * 3, dtype=torch.uint8, device="cuda")
+    st = abi.rt_stats()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), sp))
+    rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
+    o = ol.OracleScene(sd)
+    cres, cspp = (48, 27), 8
+    pc = host.default_params("hw4", **{**kw, "spp": cspp})
+    t0 = time.perf_counter()
+    o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), pc)
+    cpu_s = time.perf_counter() - t0
+    crays = o.counters().rays_traced
+    o.close(); gs.close()
+    return dict(metric="Mrays/s (distributed ray tracing, all ray types)", value=rays / (st.kernel_ms * 1e-3) / 1e6, unit="Mrays/s",
+                ms_per_frame=st.kernel_ms, passes=st.passes,
+                config=dict(workload=f"synthetic mesh, {sd.nprim} triangles, {res[0]}x{res[1]}, {spp} spp, lens 0.01 / focus 1.3, "
+                                     "light ball 0.5, glossy 0.05, reflect 0.3 (sphere) / 0.5 (floor), depth <= 10"),
+                rays=dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract),
+                trace_closest_ms=st.trace_closest_ms, trace_any_ms=st.trace_any_ms,
+                cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", cores=1, kind="port",
+                                  sample=f"the same scene and samplers at {cres[0]}x{cres[1]}, {cspp} spp, oracle port", seconds=cpu_s))
+
+
 def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_000, res=(192, 192)):
     """BASELINE configuration 4's pipeline end to end on the bundled Final scene: GPU emission of both maps, host balance,
     then the photon-mapping frame (caustic kNN r=0.1 + 50 gather rays with global kNN r=1.0, k=100, 400 light samples)."""
@@ -304,7 +340,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true", help="skip the secondary lines (kNN, 1M-triangle mesh, photon frame)")
-    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,photon_frame")
+    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,drt_1m,photon_frame")
     ap.add_argument("--knn-photons", type=int, default=10_000_000)
     ap.add_argument("--knn-queries", type=int, default=1920 * 1080)
     ap.add_argument("--cpu-sample", type=str, default="960x540")
@@ -457,6 +493,7 @@ def main():
             sec = {}
             for name, fn in (("knn", lambda: knn_secondary(gs, torch, args.knn_photons, args.knn_queries)),
                              ("mesh_1m", lambda: mesh_secondary(torch, local_rank)),
+                             ("drt_1m", lambda: drt_secondary(torch, local_rank)),
                              ("photon_frame", lambda: photon_frame_secondary(torch, local_rank))):
                 if args.only_secondary and name not in args.only_secondary.split(","):
                     continue

@@ -4,6 +4,7 @@
 // compact children]* -> quantise.  One pass per recursion depth of
 // SimpleMeshRayTrace (hw4.cpp:794-955; depth limit :796).
 #include "rt_scene.h"
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -58,18 +59,20 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const int spp = p->spp > 1 ? p->spp : 1;
     const bool drt = spp > 1 || p->lens_radius > 0.f || p->light_radius > 0.f || p->glossy > 0.f;
     if (spp > 4096) return rt_fail(RT_E_LIMIT, "rt_render: spp %d > 4096", spp);
-    const int64_t nslots = ntiles * 64;
-    const int64_t n0 = nslots * spp;
+    // the frame is traced in chunks of micro-tiles of at most 2^25 primary rays (about 6 GB of queues), so memory is
+    // bounded whatever resolution x spp is asked for; BASELINE's 4K configuration is one chunk
+    const int64_t chunk_tiles = std::max<int64_t>(1, (((int64_t)1 << 25) / spp) / 64);
     const int L = s->view.nlights;
-    const bool whole = (p->tile_size <= 0 || p->tile_nranks <= 1);
+    const bool whole = (p->tile_size <= 0 || p->tile_nranks <= 1) && ntiles <= chunk_tiles;
 
     void *d_tiles = nullptr, *rays0, *pix0, *accum, *hitany, *ctr;
     if (!whole) {
         RTCHK(s->scratch(S_TILES, (size_t)ntiles * 4, &d_tiles));
         HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)ntiles * 4, hipMemcpyHostToDevice, st), "copy tiles");
     }
-    RTCHK(s->scratch(S_RAYS0, (size_t)n0 * sizeof(rt_ray), &rays0));
-    RTCHK(s->scratch(S_PIX0, (size_t)n0 * 4, &pix0));
+    const int64_t max_n0 = std::min(ntiles, chunk_tiles) * 64 * spp;
+    RTCHK(s->scratch(S_RAYS0, (size_t)max_n0 * sizeof(rt_ray), &rays0));
+    RTCHK(s->scratch(S_PIX0, (size_t)max_n0 * 4, &pix0));
     RTCHK(s->scratch(S_ACCUM, (size_t)npix * 12, &accum));
     RTCHK(s->scratch(S_HITANY, (size_t)npix, &hitany));
     RTCHK(s->scratch(S_COUNTERS, 8 * sizeof(unsigned long long) + 16, &ctr));
@@ -93,7 +96,13 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     };
     if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
 
-    const int32_t* pixlist = (const int32_t*)pix0;      // one entry per pixel slot of this rank (zero / finalize)
+    int64_t passes = 0;
+    for (int64_t tile0 = 0; tile0 < ntiles; tile0 += chunk_tiles) {
+    const int64_t ctiles = std::min(chunk_tiles, ntiles - tile0);
+    const int32_t* c_tiles = d_tiles ? (const int32_t*)d_tiles + tile0 : nullptr;
+    const int64_t nslots = ctiles * 64;
+    const int64_t n0 = nslots * spp;
+    const int32_t* pixlist = (const int32_t*)pix0;      // one entry per pixel slot of this chunk (zero / finalize)
     const float* q_w = nullptr;          // NULL = weight 1
     const uint32_t* q_code = nullptr;    // NULL = no sample bookkeeping (the reference's single centre sample)
     if (drt) {
@@ -101,11 +110,11 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         RTCHK(s->scratch(S_W0, (size_t)n0 * 4, &w0));
         RTCHK(s->scratch(S_CODE0, (size_t)n0 * 4, &code0));
         RTCHK(s->scratch(S_PIXLIST, (size_t)nslots * 4, &pl));
-        HIPCHK(rtk_generate_drt(*cam, (const int32_t*)d_tiles, ntiles, spp, p->seed, p->lens_radius, p->focal_distance,
+        HIPCHK(rtk_generate_drt(*cam, c_tiles, ctiles, spp, p->seed, p->lens_radius, p->focal_distance,
                                 (rt_ray*)rays0, (int32_t*)pix0, (float*)w0, (uint32_t*)code0, (int32_t*)pl, st), "k_generate_drt");
         pixlist = (const int32_t*)pl; q_w = (const float*)w0; q_code = (const uint32_t*)code0;
     } else {
-        HIPCHK(rtk_generate_tiled(*cam, (const int32_t*)d_tiles, ntiles, 0.f, 0.f, (rt_ray*)rays0, (int32_t*)pix0, st), "k_generate_tiled");
+        HIPCHK(rtk_generate_tiled(*cam, c_tiles, ctiles, 0.f, 0.f, (rt_ray*)rays0, (int32_t*)pix0, st), "k_generate_tiled");
     }
     HIPCHK(rtk_zero_pixels(pixlist, nslots, (float*)accum, (uint8_t*)hitany, st), "k_zero_pixels");
 
@@ -114,7 +123,6 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const int32_t* q_pix = (const int32_t*)pix0;
     const float* q_nr = nullptr;         // NULL = start_nr ... handled below
     int64_t n = n0;
-    int64_t passes = 0;
     std::vector<float> nrfill;
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
         ++passes;
@@ -179,6 +187,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     }
     HIPCHK(rtk_finalize(pixlist, nslots, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8, st), "k_finalize");
     if (s->d_radiance_out) HIPCHK(rtk_copy_radiance(pixlist, nslots, (const float*)accum, s->d_radiance_out, st), "k_copy_radiance");
+    }   // chunks
     if (stats) {
         HIPCHK(hipEventRecord(ev1, st), "event");
         unsigned long long h[8], hw[8] = {};

@@ -2,6 +2,7 @@
 and the CPU oracle.  Bars: primary hit ids bit-exact; 8-bit radiance within 1 LSB on at most
 0.2 % of the pixels (pow() on the device is not glibc's, and the wavefront sums the same
 terms in a different association than the recursion: north_star allows a stated tolerance)."""
+import ctypes as C
 import hashlib
 import os
 
@@ -191,3 +192,21 @@ def test_distributed_ray_tracing_samplers_vs_oracle(monkey_sd, kw):
     base, _, _ = g.render(cam, host.default_params("hw4"))
     assert (base != rgb).any()
     g.close(); o.close()
+
+
+def test_chunked_frame_equals_unchunked(monkey_sd):
+    """a frame whose spp x pixels exceeds one chunk of the renderer (2^25 primary rays) is traced in several chunks of
+    micro-tiles: same bytes as the same frame sharded over ranks (whose parts each fit one chunk)"""
+    res = (640, 400)
+    kw = dict(spp=160, light_radius=0.3, seed=5, primary_only=1)      # 41 M primary rays: two chunks
+    g = host.Scene(monkey_sd)
+    cam = host.camera_for(monkey_sd, res)
+    whole, _, st = g.render(cam, host.default_params("hw4", **kw))
+    assert st.rays_primary == 160 * res[0] * res[1]
+    acc = np.zeros(res[0] * res[1] * 3, np.uint8)
+    for r in range(2):
+        p = host.default_params("hw4", tile_size=64, tile_rank=r, tile_nranks=2, **kw)
+        s2 = abi.rt_stats()
+        abi.check(g.L.rt_render(g.h, C.byref(cam), C.byref(p), acc.ctypes.data, None, C.byref(s2)))
+    assert np.array_equal(acc.reshape(res[1], res[0], 3), whole)
+    g.close()
