@@ -226,10 +226,17 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
  *   RT_TRAVERSAL_STRICT  the reference's visit order, every box and triangle test it performs
  *   RT_TRAVERSAL_FAST    (default) near-first order + culling of subtrees that cannot hold the winner,
  *                        ties resolved by the reference's visit rank: same hits, fewer tests
- * The environment variable RT_TRAVERSAL=strict|fast sets the default of new scenes.                  */
+ *   RT_TRAVERSAL_LANE    the fast rules with one path per lane instead of one per wave (per-lane record
+ *                        fetches): same hits; slower on coherent rays, faster on incoherent ones
+ * The environment variable RT_TRAVERSAL=strict|fast|lane sets the default of new scenes.
+ * RT_OPT_LANE_DEPTH: with RT_TRAVERSAL_FAST, rt_render traces the passes of recursion depth >= value (secondary
+ * rays and their shadow rays) per lane; default 2 (measured crossover on the 1 M-triangle scene);
+ * a value above max_depth keeps every pass wave-synchronous.                                          */
 #define RT_OPT_TRAVERSAL    1
 #define RT_TRAVERSAL_STRICT 0
 #define RT_TRAVERSAL_FAST   1
+#define RT_TRAVERSAL_LANE   2
+#define RT_OPT_LANE_DEPTH   3
 /* kNN algorithm of rt_photon_irradiance*, rt_photon_knn_set and the photon renderer:
  *   RT_KNN_STRICT  (default) LocatePhoton's array/heap code statement by statement: np.index in the reference's
  *                  order, irradiance summed in that order (bit-identical to the reference)

@@ -221,7 +221,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.shadow_bias = d->shadow_bias; v.refract_bias = d->refract_bias;
     s->eps_f = rt_float_above(0.000001);          // `epsilon`, hw4.cpp:18
     s->nprim = d->nprim;
-    if (const char* e = getenv("RT_TRAVERSAL")) s->fast = (strcmp(e, "strict") == 0) ? 0 : 1;
+    if (const char* e = getenv("RT_TRAVERSAL")) s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "lane") == 0) ? 2 : 1;
+    if (const char* e = getenv("RT_LANE_DEPTH")) s->lane_depth = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("RT_KNN")) s->knn_fast = (strcmp(e, "strict") == 0) ? 0 : 1;
 
     rt_scene_info& inf = s->info;
@@ -246,7 +247,8 @@ int rt_scene_destroy(rt_scene* s) {
 
 int rt_scene_set_option(rt_scene* s, int option, int value) {
     if (!s) return rt_fail(RT_E_INVALID, "rt_scene_set_option: NULL scene");
-    if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST)) { s->fast = value; return RT_OK; }
+    if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST || value == RT_TRAVERSAL_LANE)) { s->fast = value; return RT_OK; }
+    if (option == RT_OPT_LANE_DEPTH && value >= 0) { s->lane_depth = value; return RT_OK; }
     if (option == RT_OPT_KNN && (value == RT_KNN_STRICT || value == RT_KNN_FAST)) { s->knn_fast = value; return RT_OK; }
     return rt_fail(RT_E_INVALID, "rt_scene_set_option: unknown option %d / value %d", option, value);
 }

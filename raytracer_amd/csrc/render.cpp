@@ -5,6 +5,8 @@
 // SimpleMeshRayTrace (hw4.cpp:794-955; depth limit :796).
 #include "rt_scene.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -59,9 +61,11 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const int spp = p->spp > 1 ? p->spp : 1;
     const bool drt = spp > 1 || p->lens_radius > 0.f || p->light_radius > 0.f || p->glossy > 0.f;
     if (spp > 4096) return rt_fail(RT_E_LIMIT, "rt_render: spp %d > 4096", spp);
-    // the frame is traced in chunks of micro-tiles of at most 2^25 primary rays (about 6 GB of queues), so memory is
+    // the frame is traced in chunks of micro-tiles of at most 2^27 primary rays (about 25 GB of queues; fewer, larger launches are faster: every launch of incoherent
+    // rays ends in a tail of long waves), so memory is
     // bounded whatever resolution x spp is asked for; BASELINE's 4K configuration is one chunk
-    const int64_t chunk_tiles = std::max<int64_t>(1, (((int64_t)1 << 25) / spp) / 64);
+    const int chunk_log2 = [] { const char* e = getenv("RT_CHUNK_LOG2"); const int v = e ? atoi(e) : 27; return v < 12 || v > 40 ? 27 : v; }();
+    const int64_t chunk_tiles = std::max<int64_t>(1, (((int64_t)1 << chunk_log2) / spp) / 64);
     const int L = s->view.nlights;
     const bool whole = (p->tile_size <= 0 || p->tile_nranks <= 1) && ntiles <= chunk_tiles;
 
@@ -97,6 +101,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
 
     int64_t passes = 0;
+    std::vector<int64_t> pass_n;      // rays of every pass (RT_TRACE_PASSES=1 prints them with the kernel times)
     for (int64_t tile0 = 0; tile0 < ntiles; tile0 += chunk_tiles) {
     const int64_t ctiles = std::min(chunk_tiles, ntiles - tile0);
     const int32_t* c_tiles = d_tiles ? (const int32_t*)d_tiles + tile0 : nullptr;
@@ -125,7 +130,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     int64_t n = n0;
     std::vector<float> nrfill;
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
-        ++passes;
+        ++passes; pass_n.push_back(n);
         const bool spawn = !p->primary_only && depth < p->max_depth;
         void *hits, *srays, *sact, *occ, *contrib, *flags = nullptr, *bsums = nullptr, *pairs;
         RTCHK(s->scratch(S_PAIRS, (size_t)((n + 255) / 256) * 8 + 16, &pairs));
@@ -139,14 +144,14 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
         }
         RTCHK(mark());
-        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, s->fast, (rt_hit*)hits, st), "k_trace_closest");
+        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, (s->fast == 1 && depth >= s->lane_depth) ? 2 : s->fast, (rt_hit*)hits, st), "k_trace_closest");
         RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
                                (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, q_code, p->seed, p->light_radius, st), "k_shade_flags");
         RTCHK(mark());
         if (L > 0)
-            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, s->fast, (uint8_t*)occ, st), "k_trace_any");
+            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, (s->fast == 1 && depth >= s->lane_depth) ? 2 : s->fast, (uint8_t*)occ, st), "k_trace_any");
         RTCHK(mark());
         if (d_work) {
             HIPCHK(rtk_trace_work(s->view, q_rays, q_pix, nullptr, n, s->eps_f, s->fast, 0, d_work, st), "k_trace_work");
@@ -210,6 +215,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             HIPCHK(hipEventElapsedTime(&b, kev[i + 2], kev[i + 3]), "event time");
             stats->trace_closest_ms += a; stats->trace_any_ms += b;
             stats->trace_closest_launches += 1; stats->trace_any_launches += (L > 0) ? 1 : 0;
+            if (getenv("RT_TRACE_PASSES"))
+                fprintf(stderr, "pass %zu: %lld rays, closest %.3f ms, any %.3f ms\n", i / 4, (long long)pass_n[i / 4], a, b);
         }
         for (hipEvent_t e : kev) (void)hipEventDestroy(e);
     }

@@ -23,7 +23,8 @@ struct rt_scene {
     DevSceneView view;
     float eps_f = 0.f;
     int knn_fast = 0;                 // kNN: 0 = strict (default: it is also the faster one), 1 = cooperative set kernel
-    int fast = 1;                     // traversal: 1 = ordered + culled, 0 = strict reference order
+    int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
+    int fast = 1;                     // traversal: 1 = ordered + culled, 2 = the same per lane, 0 = strict reference order
     rt_scene_info info;
     std::vector<rt_light> host_lights;
     std::vector<void*> allocs;

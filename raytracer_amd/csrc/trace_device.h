@@ -352,6 +352,129 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
     }
 }
 
+// ---------------------------------------------------------------------------
+// FAST traversal, PER-LANE form, for rays that are not coherent across a wave (reflection / glossy bounces,
+// shadow rays of scattered hit points).  traverse_fast makes the wave walk the union of its 64 rays' paths, which
+// is the right trade while the paths overlap; when they do not, the union is ~64 paths long.  Here every lane
+// walks its own path through the layout of its own octant: the skip pointers make that a plain loop (no stack,
+// no re-activation bookkeeping), records are fetched with per-lane vector loads.  The accept rule, the culling
+// inequalities, the group test and the tie-break by visit rank are those of traverse_fast, so a ray gets the
+// same answer from either (tests/test_gpu_trace.py runs both against the oracle).
+// Loop shape ("while-while"): each lane advances to its next leaf group that survives the box tests, then all
+// lanes that have one test its <= RT_GROUP triangles; the wave leaves when no lane has work left.
+template <bool ANY>
+__device__ __forceinline__ void traverse_lane(const DevSceneView& sc, const Rayf& r, bool valid,
+                                              float eps_f, float tmax, bool use_tmax,
+                                              Closest& best, bool& occluded) {
+    const RayAux aux = ray_aux(r);
+    const int oct = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
+    const DevNode* __restrict__ nodes = sc.nodes_oct[0];
+#pragma unroll
+    for (int o = 1; o < 8; ++o) if (oct == o) nodes = sc.nodes_oct[o];
+    const float far_limit = ANY ? (use_tmax ? tmax : 1e9f) : 0.f;
+    const int nn = sc.nnodes;
+    int i = valid ? 0 : nn;            // node cursor
+    int g = 0, gend = 0;               // group cursor inside the current leaf
+    int gbase = 0, lf = 0, lend = 0;   // the current leaf's first group / first record / end of records
+    float reach = 0.f;
+    for (;;) {
+        int t0 = 0, t1 = 0;
+        while (t0 == t1 && (g < gend || i < nn)) {
+            if (g < gend) {
+                const DevLeafGroup gp = sc.leaf_groups[g];
+                bool ghit = true;
+                if (aux.plain) {
+                    float lat = 2.0f * gp.gm;
+                    if (gp.pad[0] != 0.0f) {
+                        const float c = __builtin_fabsf(r.dx * gp.axis[0] + r.dy * gp.axis[1] + r.dz * gp.axis[2]) * aux.rlen;
+                        const float cc = __builtin_fminf(c, 1.0f);
+                        const float lb = cc * gp.cos_t - sqrt_rn(1.0f - cc * cc) * gp.sin_t;
+                        const float detmin = __builtin_fmaxf(gp.area2_min * lb * aux.dlen * 0.999f, 1e-6f);
+                        lat = 1.2e-6f * gp.gm / detmin;
+                    }
+                    const float sl = (lat + 2e-5f) * reach + 1e-6f;
+                    const float x0 = (gp.lo[0] - sl - r.ox) * aux.rx, x1 = (gp.hi[0] + sl - r.ox) * aux.rx;
+                    const float y0 = (gp.lo[1] - sl - r.oy) * aux.ry, y1 = (gp.hi[1] + sl - r.oy) * aux.ry;
+                    const float z0 = (gp.lo[2] - sl - r.oz) * aux.rz, z1 = (gp.hi[2] + sl - r.oz) * aux.rz;
+                    const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+                    const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+                    const float limit = ANY ? far_limit : best.len;
+                    if (ex < en || ex * aux.dlen < 0.0f || en * aux.dlen > limit) ghit = false;
+                }
+                if (ghit) {
+                    t0 = lf + (g - gbase) * RT_GROUP;
+                    t1 = (t0 + RT_GROUP < lend) ? t0 + RT_GROUP : lend;
+                }
+                g = g + 1;
+            } else {
+                const DevNode nd = nodes[i];
+                float enter, exit;
+                bool hit = box_fast(nd, r, aux, enter, exit);
+                float lel = 0.f, lxl = 0.f;
+                if (hit && aux.plain) {
+                    const float el = enter * aux.dlen, xl = exit * aux.dlen;
+                    lel = __builtin_fabsf(el); lxl = __builtin_fabsf(xl);
+                    const float slack = nd.margin * (lel + lxl) + 1e-6f;
+                    const float limit = ANY ? far_limit : best.len;
+                    if (xl + slack < 0.0f || el - slack > limit) hit = false;
+                }
+                if (!hit) { i = nd.skip; }
+                else {
+                    i = i + 1;
+                    if (nd.meta & 0x100) {
+                        gbase = nd.group_first; g = gbase; gend = gbase + (nd.leaf_count + RT_GROUP - 1) / RT_GROUP;
+                        lf = nd.leaf_first; lend = lf + nd.leaf_count;
+                        reach = aux.plain ? lel + lxl + 2.0f * ((nd.hi[0] - nd.lo[0]) + (nd.hi[1] - nd.lo[1]) + (nd.hi[2] - nd.lo[2])) : 0.f;
+                    }
+                }
+            }
+        }
+        if (__ballot(t0 < t1) == 0ull) break;
+        for (int ti = t0; ti < t1; ++ti) {
+            const DevLeafTri* __restrict__ t = sc.leaf_tris + ti;
+            if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+            const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
+            const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
+            const float pvx = r.dy * e2z - r.dz * e2y;
+            const float pvy = r.dz * e2x - r.dx * e2z;
+            const float pvz = r.dx * e2y - r.dy * e2x;
+            const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+            if (__builtin_fabsf(det) < eps_f) continue;
+            const float ri = __builtin_amdgcn_rcpf(det);
+            const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
+            const float du = tx * pvx + ty * pvy + tz * pvz;
+            const float ua = du * ri;
+            if ((ua < -1e-30f) || (ua > 1.00001f)) continue;
+            const float qx = ty * e1z - tz * e1y;
+            const float qy = tz * e1x - tx * e1z;
+            const float qz = tx * e1y - ty * e1x;
+            const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
+            const float dt = e2x * qx + e2y * qy + e2z * qz;
+            const float va = dv * ri, ta = dt * ri;
+            if ((va < -1e-30f) || (ua + va > 1.00002f) || (ta < -1e-30f)) continue;
+            // the reference's exact sequence for the survivors (hw4.cpp:211-230)
+            const float detInv = 1.0f / det;
+            const float u = du * detInv;
+            if (u < 0 || u > 1.0f) continue;
+            const float v = dv * detInv;
+            if (v < 0 || u + v > 1.0f) continue;
+            const float tt = dt * detInv;
+            if (tt < 0) continue;
+            const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
+            const float len = dist_to(r, px, py, pz);
+            if (ANY) {
+                if (len < far_limit && len >= sc.tol_f) { occluded = true; i = nn; g = gend; break; }
+            } else {
+                if ((len < best.len || (len == best.len && t->rank < best.rank)) && len >= sc.tol_f &&
+                    (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
+                    best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                    best.rank = t->rank;
+                }
+            }
+        }
+    }
+}
+
 // primitives outside every tree, in index order (the whole scene for final.cpp)
 template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void loose_prims(const DevSceneView& sc, const Rayf& r, bool valid,

@@ -130,7 +130,8 @@ class Scene:
     def set_traversal(self, mode):
         """"strict" (reference order, no culling) or "fast" (default)."""
         abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_TRAVERSAL,
-                                             abi.RT_TRAVERSAL_STRICT if mode == "strict" else abi.RT_TRAVERSAL_FAST))
+                                             {"strict": abi.RT_TRAVERSAL_STRICT, "fast": abi.RT_TRAVERSAL_FAST,
+                                              "lane": abi.RT_TRAVERSAL_LANE}[mode]))
 
     def set_knn(self, mode):
         """"strict" (the reference's list order, bit-identical irradiance) or "fast" (same photon set; default)."""

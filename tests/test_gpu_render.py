@@ -30,7 +30,7 @@ def _assert_rgb_close(got, want):
     return int((d > 0).sum())
 
 
-@pytest.fixture(scope="module", params=["fast", "strict"])
+@pytest.fixture(scope="module", params=["fast", "strict", "lane"])
 def gscene(monkey_sd, request):
     s = host.Scene(monkey_sd)
     s.set_traversal(request.param)
@@ -194,19 +194,17 @@ def test_distributed_ray_tracing_samplers_vs_oracle(monkey_sd, kw):
     g.close(); o.close()
 
 
-def test_chunked_frame_equals_unchunked(monkey_sd):
-    """a frame whose spp x pixels exceeds one chunk of the renderer (2^25 primary rays) is traced in several chunks of
-    micro-tiles: same bytes as the same frame sharded over ranks (whose parts each fit one chunk)"""
-    res = (640, 400)
-    kw = dict(spp=160, light_radius=0.3, seed=5, primary_only=1)      # 41 M primary rays: two chunks
+def test_chunked_frame_equals_unchunked(monkey_sd, monkeypatch):
+    """a frame of more primary rays than one chunk of the renderer (2^27 by default, RT_CHUNK_LOG2 overrides) is traced
+    in several chunks of micro-tiles: same bytes as the same frame traced at once"""
+    res = (320, 200)
+    kw = dict(spp=16, light_radius=0.3, glossy=0.05, seed=5)      # 1 M primary rays
     g = host.Scene(monkey_sd)
     cam = host.camera_for(monkey_sd, res)
-    whole, _, st = g.render(cam, host.default_params("hw4", **kw))
-    assert st.rays_primary == 160 * res[0] * res[1]
-    acc = np.zeros(res[0] * res[1] * 3, np.uint8)
-    for r in range(2):
-        p = host.default_params("hw4", tile_size=64, tile_rank=r, tile_nranks=2, **kw)
-        s2 = abi.rt_stats()
-        abi.check(g.L.rt_render(g.h, C.byref(cam), C.byref(p), acc.ctypes.data, None, C.byref(s2)))
-    assert np.array_equal(acc.reshape(res[1], res[0], 3), whole)
+    whole, ids, st = g.render(cam, host.default_params("hw4", **kw))
+    monkeypatch.setenv("RT_CHUNK_LOG2", "18")                    # 4 chunks
+    parts, ids2, st2 = g.render(cam, host.default_params("hw4", **kw))
+    assert st2.passes > st.passes and st2.rays_primary == st.rays_primary == 16 * res[0] * res[1]
+    assert st2.rays_reflect == st.rays_reflect and st2.rays_shadow == st.rays_shadow
+    assert np.array_equal(parts, whole) and np.array_equal(ids, ids2)
     g.close()
