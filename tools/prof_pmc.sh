@@ -4,7 +4,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-W="${1:-monkey_4k mesh_1m knn_10m photon_frame}"
+W="${1:-monkey_4k mesh_1m drt_1m knn_10m photon_frame}"
 for w in $W; do
   for pass in stats FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     tag=$(echo "$pass" | tr ' ' '_')

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One workload of bench.py, alone, for rocprofv3 (so a kernel name maps to one workload):
-    python3 tools/prof_target.py monkey_4k | mesh_1m | knn_10m | photon_frame"""
+    python3 tools/prof_target.py monkey_4k | mesh_1m | drt_1m | knn_10m | photon_frame"""
 import ctypes as C
 import os
 import sys
@@ -29,6 +29,9 @@ elif what == "knn_10m":
     gs = host.Scene(bench.bench_scene())
     r = bench.knn_secondary(gs, torch, 10_000_000, 1920 * 1080, steps=2)
     print("knn_10m", r["value"], r["ms_per_step"])
+elif what == "drt_1m":
+    r = bench.drt_secondary(torch, 0)
+    print("drt_1m", r["value"], r["ms_per_frame"])
 elif what == "photon_frame":
     r = bench.photon_frame_secondary(torch, 0)
     print("photon_frame", r["value"], r["lookups_per_s"])
