@@ -29,8 +29,75 @@ def host_lib():
         L.rth_write_execution_time.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int64,
                                                C.c_int32, C.c_double]
         L.rth_ssaa_downsample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        vpp = C.POINTER(C.c_void_p)
+        L.rth_scene_parse_file.argtypes = [C.c_char_p, C.c_int, C.c_int, vpp]
+        L.rth_scene_parse_text.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, vpp]
+        L.rth_scene_fill_desc.argtypes = [C.c_void_p, C.POINTER(abi.rt_scene_desc)]
+        L.rth_scene_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32)]
+        L.rth_scene_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.rth_scene_load.argtypes = [C.c_char_p, vpp]
+        L.rth_scene_free.argtypes = [C.c_void_p]
+        L.rth_scene_free.restype = None
         _HOSTLIB = L
     return _HOSTLIB
+
+
+HOST_SYMBOLS = ("rth_camera_setup", "rth_write_ppm", "rth_write_execution_time", "rth_ssaa_downsample",
+                "rth_scene_parse_file", "rth_scene_parse_text", "rth_scene_fill_desc", "rth_scene_view", "rth_scene_save",
+                "rth_scene_load", "rth_scene_free")
+FLAVOURS = {"hw4": 0, "final": 1}
+
+
+def _scene_from_handle(h, flavour):
+    """copies what an rth_scene holds into a SceneData (the arrays the C++ front end hands to rt_scene_create)"""
+    L = host_lib()
+    d = abi.rt_scene_desc()
+    if L.rth_scene_fill_desc(h, C.byref(d)):
+        raise ValueError("rth_scene_fill_desc failed")
+    n, nm, no, nl = int(d.nprim), int(d.nmaterial), int(d.nobject), int(d.nlight)
+
+    def arr(ptr, count, dtype, cols=1):
+        if count == 0:
+            return np.zeros((0, cols) if cols > 1 else (0,), dtype)
+        nbytes = count * cols * np.dtype(dtype).itemsize
+        a = np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype).copy()
+        return a.reshape(count, cols) if cols > 1 else a
+    lights = []
+    if nl:
+        la = C.cast(d.lights, C.POINTER(abi.rt_light * nl)).contents
+        for l in la:
+            lights.append(dict(type=int(l.type), pos=list(l.pos), color=list(l.color), intensity=float(l.intensity),
+                               dir1=list(l.dir1), dir2=list(l.dir2), size1=float(l.size1), size2=float(l.size2),
+                               n1=int(l.n1), n2=int(l.n2)))
+    eye = np.zeros(3, np.float32); view = np.zeros(3, np.float32)
+    fov = C.c_float(); rx = C.c_int32(); ry = C.c_int32()
+    L.rth_scene_view(h, eye.ctypes.data, view.ctypes.data, C.byref(fov), C.byref(rx), C.byref(ry))
+    return SceneData(prims=arr(d.prims, n, np.float32, 12), prim_type=arr(d.prim_type, n, np.uint8),
+                     prim_material=arr(d.prim_material, n, np.int32), materials=arr(d.materials, nm, np.float32, 10),
+                     obj_first=arr(d.obj_first, no, np.int64), obj_count=arr(d.obj_count, no, np.int64), lights=lights,
+                     eye=eye, view=view, fov=float(fov.value), resx=int(rx.value), resy=int(ry.value), flavour=flavour)
+
+
+def parse_scene_native(path=None, text=None, flavour="hw4", nthreads=0, cache_save=None, cache_load=None):
+    """the C++ front end's parser (include/rt_host.h, rth_scene_*) -> SceneData; optional binary cache round trip"""
+    L = host_lib()
+    h = C.c_void_p()
+    if cache_load is not None:
+        rc = L.rth_scene_load(os.fsencode(cache_load), C.byref(h))
+    elif path is not None:
+        rc = L.rth_scene_parse_file(os.fsencode(path), FLAVOURS[flavour], nthreads, C.byref(h))
+    else:
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        rc = L.rth_scene_parse_text(b, len(b), FLAVOURS[flavour], nthreads, C.byref(h))
+    if rc:
+        raise ValueError(f"scene parse / load failed ({rc})")
+    try:
+        if cache_save is not None and L.rth_scene_save(h, os.fsencode(cache_save)):
+            raise ValueError("rth_scene_save failed")
+        return _scene_from_handle(h, flavour)
+    finally:
+        L.rth_scene_free(h)
 
 
 def camera_setup(eye, view_raw, fov, resx, resy):

@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"librt_hip.so does not export {s}"
     assert L.rt_abi_version() == abi.RT_ABI_VERSION
     H = host.host_lib()
-    for s in ("rth_camera_setup", "rth_write_ppm", "rth_write_execution_time", "rth_ssaa_downsample"):
+    hh = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rt_host.h")).read(), flags=re.S)
+    assert set(re.findall(r"\b(rth_[a-z0-9_]+)\s*\(", hh)) == set(host.HOST_SYMBOLS)
+    for s in host.HOST_SYMBOLS:
         assert hasattr(H, s)
 
 
