@@ -4,27 +4,49 @@
 // `plane` fields as the reference, so that kNN index sets can be compared
 // index for index.  Runs once per map on the host; the heap is then uploaded.
 #include "rt_internal.h"
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
+
+// How it is run here (the result is the reference's, element for element):
+//  * the permutation `porg` carries each photon's position along with its index (16-byte records), so
+//    median_split's scans stream through memory instead of chasing 40-byte photons; the comparisons, and so
+//    the swaps, are the reference's;
+//  * after a split the two halves touch disjoint ranges of porg, disjoint heap slots and their own copy of
+//    the bounding box (the only state the recursion carries), so the large ones run on their own threads.
+
+int rt_host_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("RT_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 64 ? 64 : v; }
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::min(16u, std::max(1u, hc));
+    }();
+    return n;
+}
 
 namespace {
 
+struct Rec { float p[3]; int32_t idx; };
+struct Box { float lo[3], hi[3]; };             // bbMin / bbMax; the reference never updates them from the
+                                                // photons (photon.cpp:263-264 start inverted, :856-859 cannot fire)
+
 struct Balancer {
-    rt_photon* ph;                  // 1-based
-    std::vector<int64_t> org;       // porg: permutation being partitioned
-    std::vector<int64_t> bal;       // pbal: heap slot -> source index
-    float lo[3], hi[3];             // bbMin / bbMax; the reference never updates them from the
-                                    // photons (photon.cpp:263-264 start inverted, :856-859 cannot fire)
+    Rec* org;                       // porg, 1-based
+    int32_t* bal;                   // pbal: heap slot -> source index
+    int8_t* plane;                  // by source index
+    int64_t par_min;                // segments at least this long get a thread for one half
 
     // median_split, photon.cpp:224-254
-    void split(int64_t start, int64_t end, int64_t median, int axis) {
+    void split(int64_t start, int64_t end, int64_t median, int axis) const {
         int64_t left = start, right = end;
         while (right > left) {
-            const float v = ph[org[right]].position[axis];
+            const float v = org[right].p[axis];
             int64_t i = left - 1, j = right;
             for (;;) {
-                while (ph[org[++i]].position[axis] < v) {}
-                while (ph[org[--j]].position[axis] > v && j > left) {}
+                while (org[++i].p[axis] < v) {}
+                while (org[--j].p[axis] > v && j > left) {}
                 if (i >= j) break;
                 std::swap(org[i], org[j]);
             }
@@ -35,7 +57,7 @@ struct Balancer {
     }
 
     // balance_segment, photon.cpp:171-222
-    void segment(int64_t index, int64_t start, int64_t end) {
+    void segment(int64_t index, int64_t start, int64_t end, Box bb) const {
         const int64_t count = end - start + 1;
         int64_t median = 1;
         while (4 * median <= count) median += median;
@@ -43,51 +65,76 @@ struct Balancer {
         else median = end - median + 1;
 
         int axis = 2;
-        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const float ex = bb.hi[0] - bb.lo[0], ey = bb.hi[1] - bb.lo[1], ez = bb.hi[2] - bb.lo[2];
         if (ex > ey && ex > ez) axis = 0;
         else if (ey > ez) axis = 1;
 
         split(start, end, median, axis);
-        bal[index] = org[median];
-        ph[bal[index]].plane = (int16_t)axis;
-        const float cut = ph[bal[index]].position[axis];
+        bal[index] = org[median].idx;
+        plane[org[median].idx] = (int8_t)axis;
+        const float cut = org[median].p[axis];
 
+        std::thread other;
         if (median > start) {
             if (start < median - 1) {
-                const float keep = hi[axis];
-                hi[axis] = cut;
-                segment(2 * index, start, median - 1);
-                hi[axis] = keep;
+                Box l = bb; l.hi[axis] = cut;
+                if (count >= par_min) other = std::thread([this, index, start, median, l] { segment(2 * index, start, median - 1, l); });
+                else segment(2 * index, start, median - 1, l);
             } else {
-                bal[2 * index] = org[start];
+                bal[2 * index] = org[start].idx;
             }
         }
         if (median < end) {
             if (median + 1 < end) {
-                const float keep = lo[axis];
-                lo[axis] = cut;
-                segment(2 * index + 1, median + 1, end);
-                lo[axis] = keep;
+                Box r = bb; r.lo[axis] = cut;
+                segment(2 * index + 1, median + 1, end, r);
             } else {
-                bal[2 * index + 1] = org[end];
+                bal[2 * index + 1] = org[end].idx;
             }
         }
+        if (other.joinable()) other.join();
     }
 };
+
+template <class F>
+void parallel_ranges(int64_t n, int nthreads, F f) {
+    if (nthreads <= 1 || n < (1 << 16)) { f(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t a = n * t / nthreads, b = n * (t + 1) / nthreads;
+        if (a < b) th.emplace_back([=] { f(a, b); });
+    }
+    for (std::thread& t : th) t.join();
+}
 
 }  // namespace
 
 // photons[0] unused, photons[1..n] in storage order; on return photons[1..n] in heap order.
 void rt_photon_balance_host(rt_photon* photons, int64_t n) {
     if (n <= 1) return;                                   // photon.cpp:135
-    Balancer b;
-    b.ph = photons;
-    b.org.resize((size_t)n + 1);
-    b.bal.assign((size_t)2 * n + 4, 0);
-    for (int64_t i = 0; i <= n; ++i) b.org[(size_t)i] = i;
-    for (int k = 0; k < 3; ++k) { b.lo[k] = -1e9f; b.hi[k] = 1e9f; }
-    b.segment(1, 1, n);
+    const int nt = rt_host_threads();
+    std::vector<Rec> org((size_t)n + 1);
+    std::vector<int32_t> bal((size_t)2 * n + 4, 0);
+    std::vector<int8_t> plane((size_t)n + 1, -1);
+    parallel_ranges(n + 1, nt, [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            Rec& r = org[(size_t)i];
+            r.p[0] = photons[i].position[0]; r.p[1] = photons[i].position[1]; r.p[2] = photons[i].position[2];
+            r.idx = (int32_t)i;
+        }
+    });
+    Balancer b{org.data(), bal.data(), plane.data(), nt > 1 ? std::max<int64_t>(1 << 15, n / (4 * nt)) : INT64_MAX};
+    Box bb;
+    for (int k = 0; k < 3; ++k) { bb.lo[k] = -1e9f; bb.hi[k] = 1e9f; }
+    b.segment(1, 1, n, bb);
+    std::vector<Rec>().swap(org);
     // photon.cpp:145-165 permutes in place; the net effect is new[j] = old[pa1[j]]
     std::vector<rt_photon> old(photons, photons + n + 1);
-    for (int64_t j = 1; j <= n; ++j) photons[j] = old[(size_t)b.bal[(size_t)j]];
+    parallel_ranges(n, nt, [&](int64_t a, int64_t c) {
+        for (int64_t j = a + 1; j <= c; ++j) {
+            const int32_t src = bal[(size_t)j];
+            photons[j] = old[(size_t)src];
+            if (plane[(size_t)src] >= 0) photons[j].plane = (int16_t)plane[(size_t)src];
+        }
+    });
 }

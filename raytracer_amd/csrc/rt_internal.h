@@ -126,6 +126,7 @@ struct HostFlatScene {
 int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string* err);
 // photon_build.cpp
 void rt_photon_balance_host(rt_photon* photons, int64_t n);
+int rt_host_threads();     // threads of the host-side builders: RT_HOST_THREADS, else min(16, cores)
 
 // smallest float f such that (double)f > t   (so  (double)x > t  <=>  x >= f  for every float x)
 float rt_float_above(double t);

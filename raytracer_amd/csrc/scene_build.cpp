@@ -7,8 +7,13 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 namespace {
 
@@ -30,12 +35,18 @@ struct BuildNode {
     // filled while flattening in reference order, reused by the other seven layouts
     int32_t leaf_first = 0, group_first = 0;
     float margin = 0.f;
+    // a leaf's records and groups, made in parallel (ranks relative to the leaf), appended in reference order
+    std::vector<DevLeafTri> tris;
+    std::vector<DevLeafGroup> groups;
 };
 
+// The two subtrees of a node are independent (own primitive lists, own counters folded in at the end), so large
+// ones are built on their own threads; the tree does not depend on the schedule.
 struct Builder {
     const rt_prim* prims;
-    int64_t built = 0;
-    int32_t max_depth = 0;
+    size_t par_min;                  // nodes with at least this many triangles give one child to a new thread
+    std::atomic<int64_t> built{0};
+    std::atomic<int32_t> max_depth{0};
 
     // CalcBound, hw4.cpp:330-389
     void bound(BuildNode& n) const {
@@ -62,8 +73,8 @@ struct Builder {
     // BuildKD, hw4.cpp:393-490.  The reference sorts every vertex coordinate on
     // the split axis and takes element size/2; nth_element yields the same value.
     void build(BuildNode& n, int depth) {
-        if (depth > max_depth) max_depth = depth;
-        ++built;
+        for (int32_t cur = max_depth.load(); depth > cur && !max_depth.compare_exchange_weak(cur, depth);) {}
+        built.fetch_add(1);
         bound(n);
         const int ax = n.axis;
         std::vector<float> coord;
@@ -91,9 +102,16 @@ struct Builder {
         const bool subdivide = (float)both < (float)n.left->prims.size() / n.model_scale &&
                                (float)both < (float)n.right->prims.size() / n.model_scale;
         if (subdivide) {
+            const bool fork = n.prims.size() >= par_min;
             std::vector<int32_t>().swap(n.prims);       // interior lists are never read by traversal
-            build(*n.left, depth + 1);
-            build(*n.right, depth + 1);
+            if (fork) {
+                std::thread other([this, &n, depth] { build(*n.left, depth + 1); });
+                build(*n.right, depth + 1);
+                other.join();
+            } else {
+                build(*n.left, depth + 1);
+                build(*n.right, depth + 1);
+            }
         } else {
             n.leaf = true;                              // hw4.cpp:484: this node tests its own list
             n.left.reset(); n.right.reset();            // its children are never visited (hw4.cpp:827)
@@ -116,92 +134,133 @@ struct Flattener {
     // Reference order (layout 7): pre-order with the RIGHT child first, the order in which the reference
     // pops nodes (hw4.cpp:831-836).  Emits the leaf records (their index is the reference's visit rank)
     // and computes the culling slack of every subtree.
+    // the records and groups of one leaf: the reference's list order gives the rank, a Morton curve the storage order
+    void make_leaf(BuildNode& n) const {
+        struct Ref { uint32_t code; int32_t k; };
+        std::vector<Ref> refs(n.prims.size());
+        for (size_t k = 0; k < n.prims.size(); ++k) {
+            const float* f = d->prims[n.prims[k]].f;
+            uint32_t code = 0;
+            for (int ax = 0; ax < 3; ++ax) {
+                const float c = (f[ax] + f[3 + ax] + f[6 + ax]) * (1.0f / 3.0f);
+                const float lo = n.center[ax] - n.extend[ax] * 0.5f, ext = n.extend[ax] > 0.f ? n.extend[ax] : 1.f;
+                float u = (c - lo) / ext; u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
+                uint32_t q = (uint32_t)(u * 1023.0f);
+                q = (q | (q << 16)) & 0x030000FF; q = (q | (q << 8)) & 0x0300F00F;
+                q = (q | (q << 4)) & 0x030C30C3; q = (q | (q << 2)) & 0x09249249;
+                code |= q << ax;
+            }
+            refs[k] = Ref{code, (int32_t)k};
+        }
+        std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.code < b.code; });
+        float margin = 0.f;
+        n.tris.reserve(refs.size());
+        n.groups.reserve((refs.size() + RT_GROUP - 1) / RT_GROUP);
+        for (size_t g0 = 0; g0 < refs.size(); g0 += RT_GROUP) {
+            DevLeafGroup g{};
+            for (int k = 0; k < 3; ++k) { g.lo[k] = 1e30f; g.hi[k] = -1e30f; }
+            float gm = 0.f;
+            double amin = 1e300, ax[3] = {0, 0, 0};
+            std::array<std::array<double, 3>, RT_GROUP> nrm;
+            int nn = 0;
+            for (size_t j = g0; j < std::min(refs.size(), g0 + RT_GROUP); ++j) {
+                const int32_t id = n.prims[(size_t)refs[j].k];
+                const float* f = d->prims[id].f;
+                DevLeafTri t{};
+                float a[9]; fill_tri(a, f);
+                memcpy(t.v0, a, 12); memcpy(t.e1, a + 3, 12); memcpy(t.e2, a + 6, 12);
+                t.prim = id;
+                t.flags = ((double)d->materials[d->prim_material[id]].refract > 0.1) ? RT_PF_SKIP_SHADOW : 0;
+                t.rank = refs[j].k;                              // + leaf_first when the leaf is appended
+                n.tris.push_back(t);
+                for (int v = 0; v < 3; ++v)
+                    for (int k = 0; k < 3; ++k) { g.lo[k] = std::min(g.lo[k], f[3 * v + k]); g.hi[k] = std::max(g.hi[k], f[3 * v + k]); }
+                // |edge1|*|edge2| bounds the cancellation in det and in the t / u / v numerators
+                const float l1 = std::sqrt(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]);
+                const float l2 = std::sqrt(a[6] * a[6] + a[7] * a[7] + a[8] * a[8]);
+                gm = std::max(gm, l1 * l2);
+                // normal cone: det = dir . (edge2 x edge1), so |det| >= |edge1 x edge2| * |dir . n|
+                const double cx = (double)a[4] * a[8] - (double)a[5] * a[7], cy = (double)a[5] * a[6] - (double)a[3] * a[8],
+                             cz = (double)a[3] * a[7] - (double)a[4] * a[6];
+                const double ar = std::sqrt(cx * cx + cy * cy + cz * cz);
+                if (ar > 0) {
+                    amin = std::min(amin, ar);
+                    std::array<double, 3> u = {cx / ar, cy / ar, cz / ar};
+                    // normals are taken up to sign: align with the first one
+                    if (nn > 0 && u[0] * nrm[0][0] + u[1] * nrm[0][1] + u[2] * nrm[0][2] < 0) { u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; }
+                    nrm[(size_t)nn++] = u; ax[0] += u[0]; ax[1] += u[1]; ax[2] += u[2];
+                }
+            }
+            g.gm = gm;
+            const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            double cmin = 0.0;
+            if (al > 1e-12 && nn > 0) {
+                cmin = 1.0;
+                for (int q = 0; q < nn; ++q) cmin = std::min(cmin, (nrm[(size_t)q][0] * ax[0] + nrm[(size_t)q][1] * ax[1] + nrm[(size_t)q][2] * ax[2]) / al);
+                for (int k = 0; k < 3; ++k) g.axis[k] = (float)(ax[k] / al);
+            }
+            // round the cone outwards: a slightly smaller cosine, a slightly larger sine
+            cmin = std::max(0.0, cmin - 1e-4);
+            g.cos_t = (float)cmin; g.sin_t = (float)std::min(1.0, std::sqrt(std::max(0.0, 1.0 - cmin * cmin)) + 1e-4);
+            g.area2_min = nn == 0 ? 0.f : (float)(amin * (1.0 - 1e-5));
+            // the cone costs ~12 vector ops per test: only worth it where the worst-case slack (|det| = 1e-6) is not
+            // already small against the box (typical reach of a ray through the scene: a few units)
+            float ext = 0.f;
+            for (int k = 0; k < 3; ++k) ext = std::max(ext, g.hi[k] - g.lo[k]);
+            g.pad[0] = (2.0f * gm * 4.0f > 0.1f * ext) ? 1.0f : 0.0f;
+            margin = std::max(margin, gm);
+            n.groups.push_back(g);
+        }
+        n.margin = margin;
+    }
+
+    static void collect_leaves(BuildNode& n, std::vector<BuildNode*>& leaves) {
+        if (n.leaf) { leaves.push_back(&n); return; }
+        collect_leaves(*n.right, leaves);
+        collect_leaves(*n.left, leaves);
+    }
+
+    // every leaf's records, in parallel (leaves are dealt round-robin: neighbours have similar sizes), then placed
+    // in the reference's leaf order (leaf_first = the reference's visit rank of the leaf's first record)
+    void make_leaves(BuildNode& root) const {
+        std::vector<BuildNode*> leaves;
+        collect_leaves(root, leaves);
+        const int nt = leaves.size() < 256 ? 1 : rt_host_threads();
+        auto each = [&](auto fn) {
+            if (nt <= 1) { for (BuildNode* l : leaves) fn(*l); return; }
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t)
+                th.emplace_back([&leaves, &fn, t, nt] { for (size_t i = (size_t)t; i < leaves.size(); i += (size_t)nt) fn(*leaves[i]); });
+            for (std::thread& t : th) t.join();
+        };
+        each([this](BuildNode& l) { make_leaf(l); });
+        size_t refs = out->leaf_tris.size(), groups = out->leaf_groups.size();
+        for (BuildNode* l : leaves) {
+            l->leaf_first = (int32_t)refs; l->group_first = (int32_t)groups;
+            refs += l->tris.size(); groups += l->groups.size();
+        }
+        out->leaf_tris.resize(refs);
+        out->leaf_groups.resize(groups);
+        each([this](BuildNode& l) {
+            for (DevLeafTri& t : l.tris) t.rank += l.leaf_first;
+            if (!l.tris.empty()) memcpy(&out->leaf_tris[(size_t)l.leaf_first], l.tris.data(), l.tris.size() * sizeof(DevLeafTri));
+            if (!l.groups.empty()) memcpy(&out->leaf_groups[(size_t)l.group_first], l.groups.data(), l.groups.size() * sizeof(DevLeafGroup));
+            std::vector<DevLeafTri>().swap(l.tris);
+            std::vector<DevLeafGroup>().swap(l.groups);
+        });
+    }
+
+    // Reference order (layout 7): pre-order with the RIGHT child first, the order in which the reference
+    // pops nodes (hw4.cpp:831-836); folds the culling slack of every subtree.
     int32_t emit_reference(BuildNode& n, int depth) {
         std::vector<DevNode>& nodes = out->nodes[7];
         const int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
-        float margin = 0.f;
-        if (n.leaf) {
-            n.leaf_first = (int32_t)out->leaf_tris.size();
-            n.group_first = (int32_t)out->leaf_groups.size();
-            // records of this leaf, in the reference's list order (rank), then sorted along a Morton curve
-            struct Ref { uint32_t code; int32_t k; };
-            std::vector<Ref> refs(n.prims.size());
-            for (size_t k = 0; k < n.prims.size(); ++k) {
-                const float* f = d->prims[n.prims[k]].f;
-                uint32_t code = 0;
-                for (int ax = 0; ax < 3; ++ax) {
-                    const float c = (f[ax] + f[3 + ax] + f[6 + ax]) * (1.0f / 3.0f);
-                    const float lo = n.center[ax] - n.extend[ax] * 0.5f, ext = n.extend[ax] > 0.f ? n.extend[ax] : 1.f;
-                    float u = (c - lo) / ext; u = u < 0.f ? 0.f : (u > 1.f ? 1.f : u);
-                    uint32_t q = (uint32_t)(u * 1023.0f);
-                    q = (q | (q << 16)) & 0x030000FF; q = (q | (q << 8)) & 0x0300F00F;
-                    q = (q | (q << 4)) & 0x030C30C3; q = (q | (q << 2)) & 0x09249249;
-                    code |= q << ax;
-                }
-                refs[k] = Ref{code, (int32_t)k};
-            }
-            std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.code < b.code; });
-            for (size_t g0 = 0; g0 < refs.size(); g0 += RT_GROUP) {
-                DevLeafGroup g{};
-                for (int k = 0; k < 3; ++k) { g.lo[k] = 1e30f; g.hi[k] = -1e30f; }
-                float gm = 0.f;
-                double amin = 1e300, ax[3] = {0, 0, 0};
-                std::vector<std::array<double, 3>> nrm;
-                for (size_t j = g0; j < std::min(refs.size(), g0 + RT_GROUP); ++j) {
-                    const int32_t id = n.prims[(size_t)refs[j].k];
-                    const float* f = d->prims[id].f;
-                    DevLeafTri t{};
-                    float a[9]; fill_tri(a, f);
-                    memcpy(t.v0, a, 12); memcpy(t.e1, a + 3, 12); memcpy(t.e2, a + 6, 12);
-                    t.prim = id;
-                    t.flags = ((double)d->materials[d->prim_material[id]].refract > 0.1) ? RT_PF_SKIP_SHADOW : 0;
-                    t.rank = n.leaf_first + refs[j].k;
-                    out->leaf_tris.push_back(t);
-                    for (int v = 0; v < 3; ++v)
-                        for (int k = 0; k < 3; ++k) { g.lo[k] = std::min(g.lo[k], f[3 * v + k]); g.hi[k] = std::max(g.hi[k], f[3 * v + k]); }
-                    // |edge1|*|edge2| bounds the cancellation in det and in the t / u / v numerators
-                    const float l1 = std::sqrt(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]);
-                    const float l2 = std::sqrt(a[6] * a[6] + a[7] * a[7] + a[8] * a[8]);
-                    gm = std::max(gm, l1 * l2);
-                    // normal cone: det = dir . (edge2 x edge1), so |det| >= |edge1 x edge2| * |dir . n|
-                    const double cx = (double)a[4] * a[8] - (double)a[5] * a[7], cy = (double)a[5] * a[6] - (double)a[3] * a[8],
-                                 cz = (double)a[3] * a[7] - (double)a[4] * a[6];
-                    const double ar = std::sqrt(cx * cx + cy * cy + cz * cz);
-                    if (ar > 0) {
-                        amin = std::min(amin, ar);
-                        std::array<double, 3> u = {cx / ar, cy / ar, cz / ar};
-                        // normals are taken up to sign: align with the first one
-                        if (!nrm.empty() && u[0] * nrm[0][0] + u[1] * nrm[0][1] + u[2] * nrm[0][2] < 0) { u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; }
-                        nrm.push_back(u); ax[0] += u[0]; ax[1] += u[1]; ax[2] += u[2];
-                    }
-                }
-                g.gm = gm;
-                const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-                double cmin = 0.0;
-                if (al > 1e-12 && !nrm.empty()) {
-                    cmin = 1.0;
-                    for (const auto& u : nrm) cmin = std::min(cmin, (u[0] * ax[0] + u[1] * ax[1] + u[2] * ax[2]) / al);
-                    for (int k = 0; k < 3; ++k) g.axis[k] = (float)(ax[k] / al);
-                }
-                // round the cone outwards: a slightly smaller cosine, a slightly larger sine
-                cmin = std::max(0.0, cmin - 1e-4);
-                g.cos_t = (float)cmin; g.sin_t = (float)std::min(1.0, std::sqrt(std::max(0.0, 1.0 - cmin * cmin)) + 1e-4);
-                g.area2_min = nrm.empty() ? 0.f : (float)(amin * (1.0 - 1e-5));
-                // the cone costs ~12 vector ops per test: only worth it where the worst-case slack (|det| = 1e-6) is not
-                // already small against the box (typical reach of a ray through the scene: a few units)
-                float ext = 0.f;
-                for (int k = 0; k < 3; ++k) ext = std::max(ext, g.hi[k] - g.lo[k]);
-                g.pad[0] = (2.0f * gm * 4.0f > 0.1f * ext) ? 1.0f : 0.0f;
-                margin = std::max(margin, gm);
-                out->leaf_groups.push_back(g);
-            }
-        } else {
+        if (!n.leaf) {
             emit_reference(*n.right, depth + 1);
             emit_reference(*n.left, depth + 1);
-            margin = std::max(n.left->margin, n.right->margin);
+            n.margin = std::max(n.left->margin, n.right->margin);
         }
-        n.margin = margin;
         fill(nodes[(size_t)me], n, depth);
         nodes[(size_t)me].skip = (int32_t)nodes.size();
         return me;
@@ -267,35 +326,67 @@ int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string*
         // hw4.cpp:736-738: modelScale = max(1.5, log10(count) - 1), root only
         const float tempF = (float)(std::log10((double)(int)cnt) - 1.0f);
         root.model_scale = tempF < 1.5f ? 1.5f : tempF;
-        Builder b{d->prims};
+        const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        const int nt = rt_host_threads();
+        Builder b{d->prims, nt > 1 ? std::max<size_t>((size_t)1 << 15, root.prims.size() / (size_t)(4 * nt)) : SIZE_MAX};
         b.build(root, 0);
-        out->kd_nodes_built += b.built;
-        out->kd_max_depth = std::max(out->kd_max_depth, b.max_depth);
-        if (b.max_depth + 1 > 250) { *err = "KD-tree deeper than 250 levels"; return RT_E_LIMIT; }
+        out->kd_nodes_built += b.built.load();
+        out->kd_max_depth = std::max(out->kd_max_depth, b.max_depth.load());
+        if (b.max_depth.load() + 1 > 250) { *err = "KD-tree deeper than 250 levels"; return RT_E_LIMIT; }
+        const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t1 = now();
         Flattener f{d, out};
+        for (int o = 0; o < 8; ++o) out->nodes[o].reserve(out->nodes[o].size() + (size_t)b.built.load());
+        f.make_leaves(root);
+        const double t2 = now();
         f.emit_reference(root, 0);
-        for (int o = 0; o < 7; ++o) f.emit_octant(root, 0, o);
+        const double t3 = now();
+        if (nt > 1 && out->nodes[7].size() > 4096) {               // the other seven layouts: one thread each
+            std::vector<std::thread> th;
+            for (int o = 0; o < 7; ++o) th.emplace_back([&f, &root, o] { f.emit_octant(root, 0, o); });
+            for (std::thread& t : th) t.join();
+        } else {
+            for (int o = 0; o < 7; ++o) f.emit_octant(root, 0, o);
+        }
+        if (timing)
+            fprintf(stderr, "object %d: %zu nodes: build %.2f s, leaf records %.2f s, reference layout %.2f s, 7 layouts %.2f s\n",
+                    (int)o, out->nodes[7].size(), t1 - t0, t2 - t1, t3 - t2, now() - t3);
         if (out->nodes[7].size() > (size_t)INT32_MAX / 2 || out->leaf_tris.size() > (size_t)INT32_MAX / 2) {
             *err = "scene exceeds 2^30 nodes or leaf references"; return RT_E_LIMIT;
         }
     }
     out->prim_normal.assign((size_t)np * 3, 0.f);
     out->prim_geom.assign((size_t)np * 4, 0.f);
+    {
+        auto tables = [d, out](int64_t a, int64_t b) {
+            for (int64_t i = a; i < b; ++i) {
+                const float* f = d->prims[i].f;
+                if (d->prim_type[i] == RT_PRIM_TRIANGLE) {
+                    // Triangle::GetNormal (hw4.cpp:122-137) re-normalises normal[0] in place on
+                    // every call; the device uses the value that sequence converges to.
+                    float nrm[3] = {f[9], f[10], f[11]};
+                    for (int it = 0; it < 16; ++it) {
+                        float prev[3] = {nrm[0], nrm[1], nrm[2]};
+                        normalize3(nrm);
+                        if (prev[0] == nrm[0] && prev[1] == nrm[1] && prev[2] == nrm[2]) break;
+                    }
+                    memcpy(&out->prim_normal[(size_t)i * 3], nrm, 12);
+                } else if (d->prim_type[i] == RT_PRIM_SPHERE) {
+                    memcpy(&out->prim_geom[(size_t)i * 4], f, 16);
+                }
+            }
+        };
+        const int nt = np < (1 << 16) ? 1 : rt_host_threads();
+        if (nt <= 1) tables(0, np);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(tables, np * t / nt, np * (t + 1) / nt);
+            for (std::thread& t : th) t.join();
+        }
+    }
     for (int64_t i = 0; i < np; ++i) {
         const float* f = d->prims[i].f;
-        if (d->prim_type[i] == RT_PRIM_TRIANGLE) {
-            // Triangle::GetNormal (hw4.cpp:122-137) re-normalises normal[0] in place on
-            // every call; the device uses the value that sequence converges to.
-            float nrm[3] = {f[9], f[10], f[11]};
-            for (int it = 0; it < 16; ++it) {
-                float prev[3] = {nrm[0], nrm[1], nrm[2]};
-                normalize3(nrm);
-                if (prev[0] == nrm[0] && prev[1] == nrm[1] && prev[2] == nrm[2]) break;
-            }
-            memcpy(&out->prim_normal[(size_t)i * 3], nrm, 12);
-        } else if (d->prim_type[i] == RT_PRIM_SPHERE) {
-            memcpy(&out->prim_geom[(size_t)i * 4], f, 16);
-        }
         if (in_tree[(size_t)i]) continue;
         if (d->prim_type[i] != RT_PRIM_TRIANGLE && d->prim_type[i] != RT_PRIM_SPHERE) continue;  // disabled
         DevLoose l{};

@@ -164,3 +164,35 @@ def test_ppm_writer_and_log(tmp_path):
     host.host_lib().rth_ssaa_downsample(src.ctypes.data, 4, 6, 2, dst.ctypes.data)
     want = src.reshape(3, 2, 2, 2, 3).astype(np.int32).transpose(0, 2, 1, 3, 4).reshape(3, 2, 4, 3).sum(2) // 4
     assert np.array_equal(dst, want)
+
+
+def test_host_builders_do_not_depend_on_the_thread_count(tmp_path):
+    """the KD build / flatten and the photon balance fork threads for large subtrees (RT_HOST_THREADS): the arrays must
+    be the same whatever the schedule.  Separate processes because the thread count is read once."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from raytracer_amd import abi, host, synth
+f = host.host_flatten(synth.mesh_scene(300, 150))
+h = hashlib.sha256()
+for k in ("lohi", "skip", "meta", "leaf_first", "leaf_count", "leaf_prim", "loose", "leaf_tri"):
+    h.update(np.ascontiguousarray(f[k]).tobytes())
+rng = np.random.default_rng(1)
+n = 300000
+a = np.zeros(n + 1, abi.photon_dtype)
+a["position"][1:] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+a["position"][1:n // 10, 1] = 0.25
+abi.check(abi.load().rt_host_photon_balance(a.ctypes.data, n))
+h.update(a.tobytes())
+print(f["info"].kd_nodes_built, f["info"].kd_max_depth, h.hexdigest())
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for nt in ("1", "3", "8"):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "RT_HOST_THREADS": nt}, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs
