@@ -164,8 +164,13 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
         run()
     e1.record(st); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    # algorithmic bytes per lookup: 24 B in + 16 B x heap nodes visited + 12 B x found + 12 B out;
-    # visits/found counted by the CPU oracle on a sample of the same queries
+    # algorithmic bytes per lookup: 24 B in + 16 B x heap nodes visited + 12 B x found + 12 B out, with the visits
+    # THIS kernel performs: one counted launch (untimed) -- phase-1 record fetches of every lane + the nodes of the shared walks
+    # summed over the lanes that were inside the subtree.  The reference's own visit count (CPU oracle, a sample of the same
+    # queries) is reported beside it.
+    scene_handle.knn_stats(True)
+    run(); torch.cuda.synchronize()
+    ks = scene_handle.knn_stats(False)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     ns = min(2000, n_queries)
@@ -176,7 +181,15 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     ol.oracle().orc_pmap_knn(a.ctypes.data, n_photons, qs.ctypes.data, ns, k, radius, idx.ctypes.data, d2.ctypes.data,
                              fnd.ctypes.data, None, C.byref(vis))
     cpu_s = time.perf_counter() - t0
-    visits = vis.value / ns
+    ref_visits = vis.value / ns
+    if ks[6] > 0:          # the wave-shared kernels ran
+        visits = float(ks[0] + ks[12]) / n_queries
+        detail = dict(kernel="k_irr_main", waves=int(ks[6]), phase1_fetches_per_lookup=float(ks[0]) / n_queries,
+                      walk_nodes_per_wave=float(ks[1] + ks[3]) / float(ks[6]), inserted_per_wave=float(ks[2]) / float(ks[6]),
+                      strict_redo_queries=int(ks[5]), waves_gave_up=int(ks[11]), longest_wave_ms=float(int(ks[8]) >> 24) * 1e-5)
+        tkey = "knn_10m.k_irr_main"
+    else:
+        visits, detail, tkey = ref_visits, dict(kernel="k_photon_knn"), "knn_10m.k_photon_knn"
     bytes_per = 24 + 16 * visits + 12 * float(fnd.mean()) + 12
     gbs = bytes_per * n_queries / (ms * 1e-3) / 1e9
     return dict(metric="kNN radiance lookups/s", value=n_queries / (ms * 1e-3), unit="lookups/s",
@@ -184,7 +197,8 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
                             queries=n_queries, k=k, radius=radius),
                 ms_per_step=ms, heap_build_host_s=build_s,
                 roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=_traffic("knn_10m.k_photon_knn"), visits_per_lookup=visits, bytes_per_lookup=bytes_per),
+                              traffic=_traffic(tkey), visits_per_lookup=visits, bytes_per_lookup=bytes_per,
+                              reference_visits_per_lookup=ref_visits, **detail),
                 cpu_baseline=dict(value=ns / cpu_s, unit="lookups/s", cores=1, kind="port",
                                   sample=f"{ns} of the same queries, oracle LocatePhoton"))
 

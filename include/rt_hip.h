@@ -237,19 +237,30 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
 #define RT_TRAVERSAL_FAST   1
 #define RT_TRAVERSAL_LANE   2
 #define RT_OPT_LANE_DEPTH   3
-/* kNN algorithm of rt_photon_irradiance*, rt_photon_knn_set and the photon renderer:
- *   RT_KNN_STRICT  (default) LocatePhoton's array/heap code statement by statement: np.index in the reference's
- *                  order, irradiance summed in that order (bit-identical to the reference)
- *   RT_KNN_FAST    (k <= 112) same visits, same accept test, candidates in registers of 16 cooperating
- *                  lanes: the same SET of photons; queries where a tie for the farthest candidate makes the set
- *                  depend on the heap's history are redone strictly; irradiance adds the same photons in another
- *                  order (float association only).  Measured 14 % SLOWER than strict on MI355X (both are bound
- *                  by vector-instruction issue), so it is an option, not the default.  RT_KNN=strict|fast sets
- *                  the default of new scenes.                                                                  */
+/* Algorithm of the radiance estimate (rt_photon_irradiance*, the photon renderer) and of rt_photon_knn_set:
+ *   RT_KNN_STRICT  LocatePhoton's array / heap code statement by statement, one query per lane: np.index in the
+ *                  reference's order, irradiance summed in that order (bit-identical to the reference).
+ *                  rt_photon_knn / rt_photon_knn_dev always run this one.
+ *   RT_KNN_FAST    (default, k <= 112) the SET the reference finds, by other means.  Irradiance: 64 neighbouring
+ *                  queries share one walk of the photon heap, each keeps the k smallest dist2 in registers
+ *                  (DESIGN 4.3c); rt_photon_knn_set: 16 lanes per query with the reference's visits.
+ *                  Queries whose set depends on the reference's heap history (exact ties), and waves whose walk
+ *                  does not end within its budget, are redone strictly.  The irradiance adds the same photons in
+ *                  another order: equal up to float association (<= 1e-5 relative in the tests).
+ * RT_KNN=strict|fast sets the default of new scenes.                                                          */
 #define RT_OPT_KNN          2
 #define RT_KNN_STRICT       0
 #define RT_KNN_FAST         1
+/* RT_OPT_KNN_STATS (measurement only; no counterpart): 1 = zero the work counters of the RT_KNN_FAST irradiance kernels
+ * and count from now on, 0 = stop.  rt_scene_knn_stats reads them (after a device synchronise):
+ *   [0] phase-1 record fetches, all lanes   [1] phase-2 node visits, per wave   [2] photons inserted into some list
+ *   [3] phase-3 node visits, per wave       [4] photons that were a member for some lane
+ *   [5] queries handed to the strict kernel [6] waves   [7] sum of wave times in 10 ns ticks
+ *   [8] longest wave time << 24 | its phase-2 visits   [9] waves > 1 ms   [10] waves > 10 ms   [11] waves that gave up
+ *   [12] phase-2/3 node visits summed over the lanes that were inside the subtree (the per-lane algorithmic count) */
+#define RT_OPT_KNN_STATS    4
 int rt_scene_set_option(rt_scene* s, int option, int value);
+int rt_scene_knn_stats(rt_scene* s, int64_t out16[16]);
 
 
 /* Host-only view of what rt_scene_create builds and uploads (no GPU needed):

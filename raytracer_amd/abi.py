@@ -19,6 +19,7 @@ RT_PMAP_GLOBAL, RT_PMAP_CAUSTIC = 0, 1
 RT_OPT_TRAVERSAL, RT_TRAVERSAL_STRICT, RT_TRAVERSAL_FAST, RT_TRAVERSAL_LANE = 1, 0, 1, 2
 RT_OPT_KNN, RT_KNN_STRICT, RT_KNN_FAST = 2, 0, 1
 RT_OPT_LANE_DEPTH = 3
+RT_OPT_KNN_STATS = 4
 
 _f, _i32, _i64, _u8 = C.c_float, C.c_int32, C.c_int64, C.c_uint8
 
@@ -84,7 +85,7 @@ assert ray_dtype.itemsize == 24 and hit_dtype.itemsize == 20 and photon_dtype.it
 # every symbol include/rt_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "rt_init", "rt_last_error", "rt_abi_version",
-    "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_set_option",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_set_option", "rt_scene_knn_stats",
     "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit", "rt_photonmap_emit_dev",
@@ -124,6 +125,7 @@ def load():
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_info_get.argtypes = [vp, C.POINTER(rt_scene_info)]
     L.rt_scene_set_option.argtypes = [vp, i32, i32]
+    L.rt_scene_knn_stats.argtypes = [vp, vp]
     L.rt_host_flatten.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(vp), C.POINTER(rt_scene_info)]
     L.rt_host_flat_get.argtypes = [vp, i32, vp, i64]
     L.rt_host_flat_get.restype = i64

@@ -245,10 +245,33 @@ int rt_scene_destroy(rt_scene* s) {
     return RT_OK;
 }
 
+int rt_scene_knn_stats(rt_scene* s, int64_t out16[16]) {
+    if (!s || !out16) return rt_fail(RT_E_INVALID, "rt_scene_knn_stats: NULL argument");
+    memset(out16, 0, 16 * sizeof(int64_t));
+    if (!s->d_knn_stats_buf) return RT_OK;
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out16, s->d_knn_stats_buf, 16 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return rt_fail(RT_E_NODEVICE, "rt_scene_knn_stats: copy failed");
+    return RT_OK;
+}
+
 int rt_scene_set_option(rt_scene* s, int option, int value) {
     if (!s) return rt_fail(RT_E_INVALID, "rt_scene_set_option: NULL scene");
     if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST || value == RT_TRAVERSAL_LANE)) { s->fast = value; return RT_OK; }
     if (option == RT_OPT_LANE_DEPTH && value >= 0) { s->lane_depth = value; return RT_OK; }
+    if (option == RT_OPT_KNN_STATS && (value == 0 || value == 1)) {
+        DeviceGuard g(s->device);
+        if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+        if (value && !s->d_knn_stats_buf) {
+            if (hipMalloc((void**)&s->d_knn_stats_buf, 16 * sizeof(unsigned long long)) != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc failed");
+            s->allocs.push_back(s->d_knn_stats_buf);
+        }
+        if (value && (hipDeviceSynchronize() != hipSuccess || hipMemset(s->d_knn_stats_buf, 0, 16 * sizeof(unsigned long long)) != hipSuccess))
+            return rt_fail(RT_E_NODEVICE, "hipMemset failed");
+        s->d_knn_stats = value ? s->d_knn_stats_buf : nullptr;               // off: the buffer keeps the last counts
+        return RT_OK;
+    }
     if (option == RT_OPT_KNN && (value == RT_KNN_STRICT || value == RT_KNN_FAST)) { s->knn_fast = value; return RT_OK; }
     return rt_fail(RT_E_INVALID, "rt_scene_set_option: unknown option %d / value %d", option, value);
 }

@@ -390,12 +390,24 @@ hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const fl
 #undef KNN_ARGS
 }
 
-// Fast path: cooperative kernel (modes 1 / 2), then the strict kernel redoes the flagged queries.  d_flagged: q bytes.
-hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
+size_t rtk_knn_fast_scratch_bytes(int64_t q) { return (((size_t)q + 255) & ~(size_t)255) + rtk_photon_irr_wave_workspace(q); }
+
+// Fast path: wave-shared kernel (mode 1) or cooperative kernel (mode 2), then the strict kernel redoes the flagged
+// queries.  d_flagged: rtk_knn_fast_scratch_bytes(q) bytes (one flag per query, then the sort's workspace).
+hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, unsigned long long* d_stats,
+                               const float* d_pos3, const float* d_nrm3,
                                int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
                                float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st) {
     if (q <= 0) return hipSuccess;
     if (k > 112 || !d_flagged) return hipErrorInvalidValue;
+    static const bool use_coop = getenv("RT_KNN_COOP") != nullptr;       // the 16-lane kernel for mode 1 too (experiments)
+    if (mode == 1 && !use_coop) {
+        // irradiance: the wave-shared kernel (kernels_photon_wave.hip), then the strict kernel redoes the flagged queries
+        void* work = (void*)(d_flagged + (((size_t)q + 255) & ~(size_t)255));
+        hipError_t e = rtk_photon_irr_wave(ph, n, half, box6, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_flagged, work, d_stats, st);
+        if (e != hipSuccess) return e;
+        return launch_knn<4>(ph, n, half, d_pos3, d_nrm3, q, k, maxDist, 1, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, d_flagged, st);
+    }
     const unsigned grid = (unsigned)((q + 3) / 4);
     if (k <= 48)
         hipLaunchKernelGGL(k_photon_knn_coop<3>, dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, mode, d_idx,

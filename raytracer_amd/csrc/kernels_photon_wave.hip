@@ -1,0 +1,444 @@
+// kernels_photon_wave.hip -- wave-shared photon-map radiance estimate on gfx950 (the RT_KNN_FAST irradiance path).
+//
+// Replaces PhotonMap::CalcIrradiance over PhotonMap::LocatePhoton (Final/photon/photon.cpp:391-441, 53-131) for
+// 64 queries at a time.  The strict kernel (kernels_photon.hip) replays the reference's list code per lane and ends
+// up bound by vector-instruction issue with 4 useful lanes per wave.  Here the 64 queries of a wave -- neighbouring
+// hit points, whose photon neighbourhoods overlap -- walk the photon kd-heap TOGETHER: records are wave-uniform
+// (scalar-path fetches), the walk is the union of the lanes' walks, and all 64 lanes do useful arithmetic on every
+// fetched photon.
+//
+// What the reference's result depends on: let S = the photons with dist2 < maxDist^2.  If |S| <= k the
+// result is S and the radius stays maxDist^2.  Otherwise, when the (k+1)-th photon is accepted the reference builds
+// its heap and drops the farthest of the first k accepted photons, E, even if the newcomer is farther
+// (photon.cpp:84-128); from then on it keeps the k nearest seen so far.  The result is therefore the k nearest of
+// S \ {E}, and the radius their largest dist2 -- given only WHICH photon E is, the visit order no longer matters.
+//   phase 1  (k_irr_phase1) per lane, in the reference's visit order with the reference's (still fixed) radius: the
+//            first k+1 accepted photons -> E, and tau = max(second largest of the first k, dist2 of the (k+1)-th)
+//            = the reference's radius right after its heap exists, an upper bound of the final one;
+//   phase 2  (k_irr_main) the wave walks the heap once: a subtree is entered if some lane's plane distance allows it
+//            (delta^2 <= tau of that lane); a photon within tau of some lane goes into every such lane's sorted list
+//            of the k smallest dist2, held in registers, and tau shrinks to the list's k-th entry;
+//   phase 3  the wave walks again with each lane's final radius T: members (dist2 <= T, not E) are counted and
+//            their power summed where the photon direction faces the surface (photon.cpp:418-429).
+// Waves are started heaviest first (largest tau of phase 1): the launch ends when its longest wave does.
+// Ties make the reference's set depend on its heap's history: a tie for the farthest of the first k, or more than
+// k photons within T, flags the query, and the strict kernel redoes it.  The sum adds the same photons in another
+// order (float association only).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cstdio>
+#include <cstdlib>
+#include "rt_internal.h"
+
+#define W_ALIVE 0x7fffffff
+#define W_DEAD  (-1)
+
+namespace {
+
+__device__ __forceinline__ float w_dist2(const float4& rec, float qx, float qy, float qz) {
+    float d1 = rec.x - qx;                      // photon.cpp:73-77: the reference's operation order
+    float dist2 = d1 * d1;
+    d1 = rec.y - qy; dist2 += d1 * d1;
+    d1 = rec.z - qz; dist2 += d1 * d1;
+    return dist2;
+}
+
+__device__ __forceinline__ float w_delta(const float4& rec, float qx, float qy, float qz) {
+    const int plane = __float_as_int(rec.w) & 3;
+    const float pp = plane == 0 ? rec.x : (plane == 1 ? rec.y : rec.z);
+    const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
+    return qp - pp;                             // photon.cpp:61
+}
+
+// sorted insertion of x into the ascending list: a chain of compare-exchanges, all in registers.  The entries are the
+// BIT PATTERNS of dist2 (>= 0, or the -inf / +inf sentinels): for those, integer order is float order, and
+// v_min_i32 / v_max_i32 need no NaN canonicalisation.  Blocks whose last entry no lane undercuts are skipped.
+template <int KMAX>
+__device__ __forceinline__ void w_insert(int (&reg)[KMAX], int x) {
+    constexpr int NB = 4, KB = KMAX / NB;
+    if (__ballot(x < reg[KMAX - 1]) == 0ull) return;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB && __ballot(x < reg[(b + 1) * KB - 1]) == 0ull) continue;
+#pragma unroll
+        for (int s = b * KB; s < (b + 1) * KB; ++s) {
+            const int cur = reg[s];
+            reg[s] = cur < x ? cur : x;
+            x = cur < x ? x : cur;
+        }
+    }
+}
+
+}  // namespace
+
+// ---- spatial order of the queries ---------------------------------------------------------------------------------
+// The 64 queries of a wave should be neighbours: the walk costs the union of their neighbourhoods.  Queries are
+// sorted along a 30-bit Morton curve over the photon map's bounding box grown by the search radius (a query outside
+// it finds nothing; a key per query, one radix sort of (key, index) pairs); the kernel reads its query through the sorted index and writes the result back to the query's own slot,
+// so callers see no reordering.
+namespace {
+
+__device__ __forceinline__ unsigned w_spread10(unsigned v) {
+    v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+struct WBox { float lo[3], inv[3]; };
+
+__global__ void __launch_bounds__(256) k_query_keys(const float* __restrict__ pos3, int64_t q, WBox box,
+                                                    unsigned* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+    unsigned key = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float u = (pos3[3 * i + a] - box.lo[a]) * box.inv[a];
+        u = u > 0.f ? (u < 1.f ? u : 1.f) : 0.f;                           // also sends NaN to 0; queries outside the grid to its rim
+        key |= w_spread10((unsigned)(u * 1023.0f)) << a;
+    }
+    keys[i] = key; vals[i] = (int32_t)i;
+}
+
+size_t w_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+
+// ---- phase 1 -----------------------------------------------------------------------------------------------------
+// out_E: the evicted photon (>= 1), -1 = the reference's heap never exists (|S| <= k), -2 = ambiguous (strict redo).
+// out_tau: the radius^2 the walk starts with.  wave_w / wave_id: per wave of 64 queries (sorted order), the largest
+// tau as its bit pattern, and the wave's number -- the (key, value) pairs of the heaviest-first order.
+__global__ void __launch_bounds__(64)
+k_irr_phase1(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3, int64_t q, int k,
+             float maxDist, const int32_t* __restrict__ perm, int32_t* __restrict__ out_E, float* __restrict__ out_tau,
+             unsigned* __restrict__ wave_w, int32_t* __restrict__ wave_id, unsigned long long* __restrict__ dbg) {
+    const int lane = threadIdx.x;
+    unsigned trips = 0;
+    const int64_t qs = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = qs < q;
+    const int64_t qi = valid ? (perm ? (int64_t)perm[qs] : qs) : 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (valid) { qx = pos3[3 * qi]; qy = pos3[3 * qi + 1]; qz = pos3[3 * qi + 2]; }
+    const float r0 = maxDist * maxDist;                                    // np.dist2[0], photon.cpp:405
+    const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
+    int acc = 0, E = -1;
+    float m1 = -1.f, m2 = -1.f, dN = 0.f;
+    if (valid && n >= 1) {
+        unsigned i = 1, child = 0;
+        bool up = false;
+        for (;;) {
+            const float4 rec = *reinterpret_cast<const float4*>(ph + i);
+            ++trips;
+            if (i < uhalf) {
+                const float delta = w_delta(rec, qx, qy, qz);
+                const unsigned near = (delta > 0.0f) ? 2 * i + 1 : 2 * i;
+                if (!up) { i = near; continue; }
+                if (child == near && delta * delta < r0) { i = near ^ 1u; up = false; continue; }
+            }
+            const float d2 = w_dist2(rec, qx, qy, qz);                     // both subtrees done: the node itself
+            if (d2 < r0) {
+                ++acc;
+                if (acc > k) { dN = d2; break; }
+                if (d2 > m1) { m2 = m1; m1 = d2; E = (int)i; }
+                else if (d2 > m2) m2 = d2;
+            }
+            if (i == 1) break;
+            child = i; i >>= 1; up = true;
+        }
+    }
+    const bool evict = acc > k;                                            // |S| >= k+1: the reference's heap exists
+    const bool ambiguous = evict && m1 == m2;                              // two candidates for E
+    const float tau = evict ? (m2 > dN ? m2 : dN) : r0;
+    if (valid) { out_E[qs] = ambiguous ? -2 : (evict ? E : -1); out_tau[qs] = tau; }
+    float w = (valid && !ambiguous && n >= 1) ? tau : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(w, off, 64); w = o > w ? o : w; }
+    if (lane == 0 && wave_w) { wave_w[blockIdx.x] = (unsigned)__float_as_int(w); wave_id[blockIdx.x] = (int32_t)blockIdx.x; }
+    if (dbg) {
+        unsigned long long t = trips;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0) atomicAdd(dbg + 0, t);
+    }
+}
+
+// ---- phases 2 and 3 ------------------------------------------------------------------------------------------------
+// The walk, shared by both phases: node i at `depth`, `pending` bit d = the sibling of the path's node at depth d is
+// still to be visited.  Per lane: `fail` (W_ALIVE, or the depth at which the lane left the path: it did not want that
+// subtree) and `sib`, bit d = the lane wants the pending sibling at depth d (decided at the parent).  The records of
+// both children are fetched with the parent (32 contiguous bytes), so a descent does not wait for memory.
+template <int KMAX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
+           const float* __restrict__ nrm3, int64_t q, int k, float maxDist, float* __restrict__ out_rgb,
+           const float* __restrict__ tables, uint8_t* __restrict__ flagged, const int32_t* __restrict__ perm,
+           const int32_t* __restrict__ p1_E, const float* __restrict__ p1_tau, const int32_t* __restrict__ order,
+           unsigned budget, unsigned long long* __restrict__ dbg) {
+    const int lane = threadIdx.x;
+    const long long t_begin = dbg ? wall_clock64() : 0;
+    const unsigned wv = order ? (unsigned)order[blockIdx.x] : blockIdx.x;  // heaviest waves first
+    const int64_t qs = (int64_t)wv * 64 + lane;                            // position in the spatially sorted order
+    const bool valid = qs < q;
+    const int64_t qi = valid ? (perm ? (int64_t)perm[qs] : qs) : 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    int E = -2;
+    float tau = 0.f;
+    if (valid) { qx = pos3[3 * qi]; qy = pos3[3 * qi + 1]; qz = pos3[3 * qi + 2]; E = p1_E[qs]; tau = p1_tau[qs]; }
+    const float r0 = maxDist * maxDist;
+    const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
+    const int INF_BITS = 0x7f800000;
+    bool ambiguous = valid && E == -2;
+    const bool evict = E >= 0;
+    const bool live = valid && n >= 1 && !ambiguous;
+    unsigned d_v2 = 0, d_c2 = 0, d_v3 = 0, d_m3 = 0, d_lanes = 0;          // measurement (dbg != NULL)
+
+    // ---- phase 2: k smallest dist2 of S \ {E} per lane ---------------------------------------------------------
+    int reg[KMAX];                                                         // bit patterns of dist2, ascending
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) reg[s] = (s < KMAX - k) ? (int)0xff800000 : INF_BITS;   // the k-th smallest is always reg[KMAX-1]
+    int cnt = 0;
+    bool bailed = false;
+    if (__ballot(live) != 0ull) {
+        int fail = live ? W_ALIVE : W_DEAD;
+        unsigned i = 1, pending = 0;
+        int depth = 0;
+        float4 rec = *reinterpret_cast<const float4*>(ph + 1);
+        for (;;) {
+            const bool internal = i < uhalf;
+            float4 cl = rec, cr = rec;
+            if (internal) { cl = *reinterpret_cast<const float4*>(ph + 2 * i); cr = *reinterpret_cast<const float4*>(ph + 2 * i + 1); }
+            const bool al = fail == W_ALIVE;
+            const float d2 = w_dist2(rec, qx, qy, qz);
+            const bool cand = al && d2 <= tau && d2 < r0 && (int)i != E;
+            if (++d_v2 > budget) { bailed = true; break; }
+            if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
+            if (__ballot(cand) != 0ull) {
+                ++d_c2;
+                cnt += cand ? 1 : 0;
+                w_insert<KMAX>(reg, cand ? __float_as_int(d2) : INF_BITS);
+                const float kth = __int_as_float(reg[KMAX - 1]);
+                tau = tau < kth ? tau : kth;
+            }
+            bool descended = false;
+            if (internal) {
+                const float delta = w_delta(rec, qx, qy, qz);
+                const bool within = delta * delta <= tau;
+                const bool wr = al && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
+                const unsigned long long wantR = __ballot(wr), wantL = __ballot(wl);
+                if ((wantL | wantR) != 0ull) {
+                    const bool both = wantL != 0ull && wantR != 0ull;
+                    // the side most lanes are on first: the lists fill with close photons early and tau shrinks
+                    const bool right_first = both ? 2 * __popcll(__ballot(al && delta > 0.0f)) > __popcll(__ballot(al)) : wantR != 0ull;
+                    ++depth;
+                    if (both) pending |= 1u << depth;
+                    if (al && !(right_first ? wr : wl)) fail = depth;
+                    rec = right_first ? cr : cl; i = 2 * i + (right_first ? 1u : 0u);
+                    descended = true;
+                }
+            }
+            if (descended) continue;
+            bool done = false;
+            for (;;) {                                                     // up to the next pending sibling some lane wants
+                while (depth > 0 && !((pending >> depth) & 1u)) { i >>= 1; --depth; }
+                if (depth == 0) { done = true; break; }
+                pending &= ~(1u << depth);
+                i ^= 1u;
+                if (fail >= depth) fail = W_ALIVE;
+                {   // does the lane want this sibling?  decided with the radius it has NOW (smaller than at the parent's visit)
+                    const float4 prec = *reinterpret_cast<const float4*>(ph + (i >> 1));
+                    const float dp = w_delta(prec, qx, qy, qz);
+                    const bool want = (i & 1u) ? (dp > 0.0f || dp * dp <= tau) : (!(dp > 0.0f) || dp * dp <= tau);
+                    if (fail == W_ALIVE && !want) fail = depth;
+                }
+                if (__ballot(fail == W_ALIVE) != 0ull) break;
+            }
+            if (done) break;
+            rec = *reinterpret_cast<const float4*>(ph + i);
+        }
+    }
+
+    // a wave whose walk does not end (queries that are not neighbours after all, or a part of the reference's heap that
+    // its stale bounding box left without spatial order) gives up and leaves its queries to the strict kernel, which
+    // spreads them over 16 waves: bounds the longest wave, which is what the launch waits for
+    if (bailed && live) ambiguous = true;
+    const int found = evict ? k : cnt;
+    const float T = evict ? __int_as_float(reg[KMAX - 1]) : r0;            // the reference's final np.dist2[0]
+
+    // ---- phase 3: members within T, their power where the photon faces the surface -----------------------------
+    float r = 0.f, g = 0.f, b = 0.f;
+    int members = 0;
+    const bool summing = live && !bailed && found >= 8;                             // literal 8, photon.cpp:411
+    if (__ballot(summing) != 0ull) {
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (summing) { nx = nrm3[3 * qi]; ny = nrm3[3 * qi + 1]; nz = nrm3[3 * qi + 2]; }
+        const float* cosT = tables; const float* sinT = tables + 256;
+        const float* cosP = tables + 512; const float* sinP = tables + 768;
+        const DevPhotonPow* __restrict__ pw = reinterpret_cast<const DevPhotonPow*>(ph + (n + 1));
+        int fail = summing ? W_ALIVE : W_DEAD;
+        unsigned i = 1, pending = 0;
+        int depth = 0;
+        float4 rec = *reinterpret_cast<const float4*>(ph + 1);
+        for (;;) {
+            const bool internal = i < uhalf;
+            float4 cl = rec, cr = rec;
+            if (internal) { cl = *reinterpret_cast<const float4*>(ph + 2 * i); cr = *reinterpret_cast<const float4*>(ph + 2 * i + 1); }
+            const bool al = fail == W_ALIVE;
+            const float d2 = w_dist2(rec, qx, qy, qz);
+            const bool member = al && d2 <= T && d2 < r0 && (int)i != E;
+            ++d_v3;
+            if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
+            if (__ballot(member) != 0ull) {
+                ++d_m3;
+                members += member ? 1 : 0;
+                const unsigned pk = (unsigned)__float_as_int(rec.w);
+                const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
+                const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
+                const bool facing = member && (dx * nx + dy * ny + dz * nz) < 0.0f;
+                if (__ballot(facing) != 0ull) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(pw + i);
+                    if (facing) { r += w4.x; g += w4.y; b += w4.z; }
+                }
+            }
+            bool descended = false;
+            if (internal) {
+                const float delta = w_delta(rec, qx, qy, qz);
+                const bool within = delta * delta <= T;
+                const bool wr = al && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
+                const unsigned long long wantR = __ballot(wr), wantL = __ballot(wl);
+                if ((wantL | wantR) != 0ull) {
+                    const bool both = wantL != 0ull && wantR != 0ull;
+                    const bool right_first = both ? false : wantR != 0ull;
+                    ++depth;
+                    if (both) pending |= 1u << depth;
+                    if (al && !(right_first ? wr : wl)) fail = depth;
+                    rec = right_first ? cr : cl; i = 2 * i + (right_first ? 1u : 0u);
+                    descended = true;
+                }
+            }
+            if (descended) continue;
+            bool done = false;
+            for (;;) {
+                while (depth > 0 && !((pending >> depth) & 1u)) { i >>= 1; --depth; }
+                if (depth == 0) { done = true; break; }
+                pending &= ~(1u << depth);
+                i ^= 1u;
+                if (fail >= depth) fail = W_ALIVE;
+                {   // does the lane want this sibling?  decided with the radius it has NOW (smaller than at the parent's visit)
+                    const float4 prec = *reinterpret_cast<const float4*>(ph + (i >> 1));
+                    const float dp = w_delta(prec, qx, qy, qz);
+                    const bool want = (i & 1u) ? (dp > 0.0f || dp * dp <= T) : (!(dp > 0.0f) || dp * dp <= T);
+                    if (fail == W_ALIVE && !want) fail = depth;
+                }
+                if (__ballot(fail == W_ALIVE) != 0ull) break;
+            }
+            if (done) break;
+            rec = *reinterpret_cast<const float4*>(ph + i);
+        }
+        if (summing && evict && members != k) ambiguous = true;            // more than k photons within T: a tie
+        const float tmp = (float)(((double)1.0f / 3.141592) / (double)T);  // (1.0f/PI)/(np.dist2[0])
+        r *= tmp; g *= tmp; b *= tmp;
+    }
+    if (dbg) {
+        const unsigned long long fl = __popcll(__ballot(valid && ambiguous));
+        if (lane == 0) {
+            atomicAdd(dbg + 1, (unsigned long long)d_v2); atomicAdd(dbg + 2, (unsigned long long)d_c2);
+            atomicAdd(dbg + 3, (unsigned long long)d_v3); atomicAdd(dbg + 4, (unsigned long long)d_m3); atomicAdd(dbg + 5, fl);
+            atomicAdd(dbg + 6, 1ull);
+            const unsigned long long dt = (unsigned long long)(wall_clock64() - t_begin);      // 100 MHz ticks
+            atomicAdd(dbg + 7, dt);
+            atomicMax(dbg + 8, (dt << 24) | (unsigned long long)(d_v2 > 0xffffffu ? 0xffffffu : d_v2));
+            if (dt > 100000ull) atomicAdd(dbg + 9, 1ull);                                      // waves longer than 1 ms
+            if (dt > 1000000ull) atomicAdd(dbg + 10, 1ull);                                    // longer than 10 ms
+            if (bailed) atomicAdd(dbg + 11, 1ull);
+            atomicAdd(dbg + 12, (unsigned long long)d_lanes);
+        }
+    }
+    if (valid) {
+        if (ambiguous) { r = 0.f; g = 0.f; b = 0.f; }
+        out_rgb[3 * qi] = r; out_rgb[3 * qi + 1] = g; out_rgb[3 * qi + 2] = b;
+        flagged[qi] = ambiguous ? 1 : 0;
+    }
+}
+
+namespace {
+struct WaveWork {            // carved from the caller's workspace
+    unsigned *keys_in, *keys_out; int32_t *vals_in, *vals_out; int32_t* p1_E; float* p1_tau;
+    unsigned *wk_in, *wk_out; int32_t *wv_in, *wv_out; void* temp; size_t temp_bytes, total;
+};
+WaveWork carve(void* base, int64_t q) {
+    WaveWork W;
+    const int64_t nw = (q + 63) / 64;
+    size_t t1 = 0, t2 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned*)nullptr, (unsigned*)nullptr, (const int32_t*)nullptr,
+                                             (int32_t*)nullptr, (int)q, 0, 30, (hipStream_t)nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t2, (const unsigned*)nullptr, (unsigned*)nullptr, (const int32_t*)nullptr,
+                                                       (int32_t*)nullptr, (int)nw, 0, 32, (hipStream_t)nullptr);
+    char* w = (char*)base;
+    auto take = [&w](size_t bytes) { char* p = w; w += w_align(bytes); return (void*)p; };
+    W.keys_in = (unsigned*)take((size_t)q * 4); W.keys_out = (unsigned*)take((size_t)q * 4);
+    W.vals_in = (int32_t*)take((size_t)q * 4); W.vals_out = (int32_t*)take((size_t)q * 4);
+    W.p1_E = (int32_t*)take((size_t)q * 4); W.p1_tau = (float*)take((size_t)q * 4);
+    W.wk_in = (unsigned*)take((size_t)nw * 4); W.wk_out = (unsigned*)take((size_t)nw * 4);
+    W.wv_in = (int32_t*)take((size_t)nw * 4); W.wv_out = (int32_t*)take((size_t)nw * 4);
+    W.temp_bytes = t1 > t2 ? t1 : t2;
+    W.temp = take(W.temp_bytes);
+    W.total = (size_t)(w - (char*)base) + 256;
+    return W;
+}
+}  // namespace
+
+// workspace of rtk_photon_irr_wave for q queries (sort keys / indices, phase-1 results, wave order, the sorts' storage)
+size_t rtk_photon_irr_wave_workspace(int64_t q) { return carve(nullptr, q).total; }
+
+// k <= 128.  d_flagged: q bytes, 1 = redo this query with the strict kernel.  d_work: rtk_photon_irr_wave_workspace(q)
+// bytes.  d_stats: NULL, or 16 counters that the kernels add to (rt_scene_knn_stats):
+//   [0] phase-1 record fetches (all lanes)   [1] phase-2 node visits (per wave)   [2] photons inserted into some list
+//   [3] phase-3 node visits   [4] photons that were a member for some lane   [5] queries flagged for the strict redo
+//   [6] waves   [7] sum of wave times, 10 ns ticks   [8] longest wave << 24 | its phase-2 visits   [9] waves > 1 ms
+//   [10] waves > 10 ms   [11] waves that gave up   [12] node visits summed over the lanes that were in the subtree
+hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, const float* d_pos3, const float* d_nrm3,
+                               int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, uint8_t* d_flagged,
+                               void* d_work, unsigned long long* d_stats, hipStream_t st) {
+    if (q <= 0) return hipSuccess;
+    if (k < 1 || k > 128 || !d_flagged || !d_work || q > 0x7fffffff) return hipErrorInvalidValue;
+    const WaveWork W = carve(d_work, q);
+    const unsigned grid = (unsigned)((q + 63) / 64);
+    static const bool no_sort = getenv("RT_KNN_NOSORT") != nullptr, no_order = getenv("RT_KNN_NOORDER") != nullptr;
+    const int32_t* perm = nullptr;
+    hipError_t e;
+    if (q > 64 && !no_sort) {
+        size_t temp = W.temp_bytes;
+        WBox box;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = (box6 ? box6[a] : 0.f) - maxDist, hi = (box6 ? box6[3 + a] : 0.f) + maxDist;
+            box.lo[a] = lo; box.inv[a] = hi > lo ? 1.0f / (hi - lo) : 0.f;
+        }
+        hipLaunchKernelGGL(k_query_keys, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, d_pos3, q, box, W.keys_in, W.vals_in);
+        e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)q, 0, 30, st);
+        if (e != hipSuccess) return e;
+        perm = W.vals_out;
+    }
+    hipLaunchKernelGGL(k_irr_phase1, dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, q, k, maxDist, perm, W.p1_E, W.p1_tau,
+                       W.wk_in, W.wv_in, d_stats);
+    const int32_t* order = nullptr;
+    if (grid > 64 && !no_order) {
+        size_t temp = W.temp_bytes;
+        e = hipcub::DeviceRadixSort::SortPairsDescending(W.temp, temp, W.wk_in, W.wk_out, W.wv_in, W.wv_out, (int)grid, 0, 32, st);
+        if (e != hipSuccess) return e;
+        order = W.wv_out;
+    }
+    // phase-2 node visits a wave may spend before it gives up (the mean is 1 000 - 3 000 at k = 100).  A wave alone on
+    // the chip walks at memory latency, ~0.8 us per visit: the budget is what the end of the launch can wait for, so a
+    // short launch gets a short one.
+    const unsigned budget = (unsigned)std::min<int64_t>(std::max<int64_t>((int64_t)grid / 2, 2048), 16384);
+    unsigned long long* dbg = d_stats;
+#define WAVE_ARGS dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_flagged, perm, \
+                  W.p1_E, W.p1_tau, order, budget, dbg
+    if (k <= 32) hipLaunchKernelGGL(k_irr_main<32>, WAVE_ARGS);
+    else if (k <= 64) hipLaunchKernelGGL(k_irr_main<64>, WAVE_ARGS);
+    else if (k <= 104) hipLaunchKernelGGL(k_irr_main<104>, WAVE_ARGS);
+    else hipLaunchKernelGGL(k_irr_main<128>, WAVE_ARGS);
+#undef WAVE_ARGS
+    return hipGetLastError();
+}

@@ -45,9 +45,12 @@ int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
     memset(dev.data(), 0, sizeof(DevPhotonPos));
     DevPhotonPow* pw = reinterpret_cast<DevPhotonPow*>(dev.data() + (size_t)n + 1);
     memset(pw, 0, sizeof(DevPhotonPow));
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     for (int64_t i = 1; i <= n; ++i) {
         const rt_photon& p = heap[i];
         DevPhotonPos& d = dev[(size_t)i];
+        for (int a = 0; a < 3; ++a)
+            if (p.position[a] > -1e30f && p.position[a] < 1e30f) { lo[a] = std::min(lo[a], p.position[a]); hi[a] = std::max(hi[a], p.position[a]); }
         memcpy(d.pos, p.position, 12); memcpy(pw[i].power, p.power, 12);
         d.packed = ((uint32_t)p.plane & 3u) | ((uint32_t)p.theta << 8) | ((uint32_t)p.phi << 16);
         pw[i].pad = 0;
@@ -57,6 +60,7 @@ int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
     HIPCHK(hipMemcpy(m.d_photons, dev.data(), dev.size() * sizeof(DevPhotonPos), hipMemcpyHostToDevice), "copy photon map");
     m.n = n;
     m.half = n / 2 - 1;                       // photon.cpp:168
+    for (int a = 0; a < 3; ++a) { m.box[a] = lo[a] <= hi[a] ? lo[a] : 0.f; m.box[3 + a] = lo[a] <= hi[a] ? hi[a] : 0.f; }
     return ensure_tables(s);
 }
 
@@ -142,8 +146,8 @@ int rt_photon_knn_set(rt_scene* s, int which, const float* pos3, int64_t q, int 
     HIPCHK(hipMemcpy(dp, pos3, (size_t)q * 12, hipMemcpyHostToDevice), "copy queries");
     const PhotonMapDev& m = s->pmap[which];
     if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
-        void* fl; RTCHK(s->scratch(S_Q_FLAG, (size_t)q, &fl));
-        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, (const float*)dp, nullptr, q, k, maxDist, 2, (int32_t*)di, (float*)dd,
+        void* fl; RTCHK(s->scratch(S_Q_FLAG, rtk_knn_fast_scratch_bytes(q), &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, m.box, s->d_knn_stats, (const float*)dp, nullptr, q, k, maxDist, 2, (int32_t*)di, (float*)dd,
                                    (int32_t*)df, (float*)dr, nullptr, s->d_dir_tables, (uint8_t*)fl, nullptr), "k_photon_knn_coop");
     } else
     HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, (const float*)dp, nullptr, q, k, maxDist, 0, (int32_t*)di, (float*)dd,
@@ -163,8 +167,8 @@ int rt_photon_irradiance_dev(rt_scene* s, int which, const float* d_pos3, const 
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
     const PhotonMapDev& m = s->pmap[which];
     if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
-        void* fl; RTCHK(s->scratch(S_Q_FLAG, (size_t)q, &fl));
-        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, d_pos3, d_nrm3, q, k, maxDist, 1, nullptr, nullptr, nullptr, nullptr,
+        void* fl; RTCHK(s->scratch(S_Q_FLAG, rtk_knn_fast_scratch_bytes(q), &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, m.box, s->d_knn_stats, d_pos3, d_nrm3, q, k, maxDist, 1, nullptr, nullptr, nullptr, nullptr,
                                    d_rgb, s->d_dir_tables, (uint8_t*)fl, (hipStream_t)stream), "k_photon_knn_coop");
         return RT_OK;
     }
@@ -188,8 +192,8 @@ int rt_photon_irradiance(rt_scene* s, int which, const float* pos3, const float*
     HIPCHK(hipMemcpy(dn, nrm3, (size_t)q * 12, hipMemcpyHostToDevice), "copy normals");
     const PhotonMapDev& m = s->pmap[which];
     if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
-        void* fl; RTCHK(s->scratch(S_Q_FLAG, (size_t)q, &fl));
-        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, (const float*)dp, (const float*)dn, q, k, maxDist, 1, nullptr, nullptr,
+        void* fl; RTCHK(s->scratch(S_Q_FLAG, rtk_knn_fast_scratch_bytes(q), &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, m.box, s->d_knn_stats, (const float*)dp, (const float*)dn, q, k, maxDist, 1, nullptr, nullptr,
                                    nullptr, nullptr, (float*)dc, s->d_dir_tables, (uint8_t*)fl, nullptr), "k_photon_knn_coop");
     } else
     HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, (const float*)dp, (const float*)dn, q, k, maxDist, 1, nullptr, nullptr,

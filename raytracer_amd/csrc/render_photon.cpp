@@ -40,8 +40,8 @@ int knn(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, i
     const PhotonMapDev& m = s->pmap[which];
     if (!m.d_photons || m.n < 1) { HIPCHK(hipMemsetAsync(rgb, 0, (size_t)q * 12, st), "memset irradiance"); return RT_OK; }
     if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
-        void* fl; RTCHK(s->scratch(P_KNN_FLAG, (size_t)q, &fl));
-        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, pos, nrm, q, k, radius, 1, nullptr, nullptr, nullptr, nullptr, rgb,
+        void* fl; RTCHK(s->scratch(P_KNN_FLAG, rtk_knn_fast_scratch_bytes(q), &fl));
+        HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, m.box, s->d_knn_stats, pos, nrm, q, k, radius, 1, nullptr, nullptr, nullptr, nullptr, rgb,
                                    s->d_dir_tables, (uint8_t*)fl, st), "k_photon_knn_coop");
         return RT_OK;
     }

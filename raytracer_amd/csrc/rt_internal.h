@@ -217,7 +217,12 @@ hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const fl
                           int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
                           float* d_r2, float* d_rgb, const float* d_tables, hipStream_t st);
 // cooperative kernel (mode 1 irradiance / mode 2 candidate set) + strict redo of the queries it flags; k <= 112
-hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
+hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, unsigned long long* d_stats, const float* d_pos3, const float* d_nrm3,
                                int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
                                float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st);
+hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, const float* d_pos3, const float* d_nrm3,
+                               int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, uint8_t* d_flagged,
+                               void* d_work, unsigned long long* d_stats, hipStream_t st);
+size_t rtk_photon_irr_wave_workspace(int64_t q);
+size_t rtk_knn_fast_scratch_bytes(int64_t q);
 #define RT_KNN_FAST_KMAX 112

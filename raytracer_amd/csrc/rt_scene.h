@@ -15,6 +15,7 @@ struct PhotonMapDev {
     DevPhoton* d_photons = nullptr;   // [n+1], heap order, slot 0 unused
     int64_t n = 0;
     int64_t half = 0;                 // half_stored_photons = n/2 - 1 (photon.cpp:168)
+    float box[6] = {0, 0, 0, 0, 0, 0};// lo[3], hi[3] of the photon positions (the query sort's grid)
 };
 
 struct rt_scene {
@@ -22,7 +23,9 @@ struct rt_scene {
     int64_t nprim = 0;
     DevSceneView view;
     float eps_f = 0.f;
-    int knn_fast = 0;                 // kNN: 0 = strict (default: it is also the faster one), 1 = cooperative set kernel
+    unsigned long long* d_knn_stats = nullptr;   // 16 work counters of the wave-shared kNN kernels, NULL = not counting (RT_OPT_KNN_STATS)
+    unsigned long long* d_knn_stats_buf = nullptr;
+    int knn_fast = 1;                 // radiance estimate: 1 = wave-shared kernel (default), 0 = strict list replay
     int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
     int fast = 1;                     // traversal: 1 = ordered + culled, 2 = the same per lane, 0 = strict reference order
     rt_scene_info info;

@@ -200,6 +200,15 @@ class Scene:
                                              {"strict": abi.RT_TRAVERSAL_STRICT, "fast": abi.RT_TRAVERSAL_FAST,
                                               "lane": abi.RT_TRAVERSAL_LANE}[mode]))
 
+    def knn_stats(self, on=None):
+        """work counters of the wave-shared radiance-estimate kernels (include/rt_hip.h, RT_OPT_KNN_STATS): on=True zeroes and
+        starts them, on=False stops; returns the 16 counters"""
+        if on is not None:
+            abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_KNN_STATS, 1 if on else 0))
+        out = np.zeros(16, np.int64)
+        abi.check(self.L.rt_scene_knn_stats(self.h, out.ctypes.data))
+        return out
+
     def set_knn(self, mode):
         """"strict" (the reference's list order, bit-identical irradiance) or "fast" (same photon set; default)."""
         abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_KNN, abi.RT_KNN_STRICT if mode == "strict" else abi.RT_KNN_FAST))

@@ -192,3 +192,30 @@ def test_lattice_of_ties_goes_through_the_strict_redo(gscene):
         assert _sets_equal(si, sd2, sf, oi, od, of) and sr.tobytes() == orr.tobytes(), (k, maxd)
         rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, k, maxd)
         assert _irr_equal(gscene, rgb, _oracle_irr(heap, qp, qn, k, maxd)), (k, maxd)
+
+
+def test_coherent_queries_share_a_walk(gscene):
+    """the wave-shared radiance estimate (RT_KNN_FAST: 64 neighbouring queries per walk, lists of the k smallest dist2 in
+    registers) on queries that ARE neighbours -- a dense patch on a wall and a dense patch in free space --
+    at every list size the kernel is instantiated for and at their edges; against the oracle's CalcIrradiance."""
+    n = 400_000
+    a = _random_map(n, 31)
+    heap = gscene.photonmap_build(abi.RT_PMAP_GLOBAL, a)
+    g = np.stack(np.meshgrid(np.linspace(-0.2, -0.1, 48), np.linspace(0.1, 0.2, 48), indexing="ij"), -1).reshape(-1, 2).astype(np.float32)
+    wall = np.stack([g[:, 0], np.full(len(g), -0.5, np.float32), g[:, 1]], 1)
+    free = np.stack([g[:, 0], g[:, 1], g[:, 0] * 0.5], 1).astype(np.float32)
+    rng = np.random.default_rng(32)
+    for k, maxd in ((8, 1.0), (32, 1.0), (33, 0.5), (64, 1.0), (65, 1.0), (100, 1.0), (104, 1.0), (105, 0.3), (112, 1.0),
+                    (100, 0.02), (100, 0.004)):
+        for qp in (wall, free):
+            qp = np.ascontiguousarray(qp[rng.permutation(len(qp))])          # the product sorts them itself
+            qn = rng.normal(size=qp.shape).astype(np.float32)
+            rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, k, maxd)
+            want = _oracle_irr(heap, qp, qn, k, maxd)
+            assert _irr_equal(gscene, rgb, want), (k, maxd, float(np.abs(rgb - want).max()))
+    # queries far outside the map, at infinity and NaN find nothing and disturb nobody
+    qp = np.concatenate([wall[:500], np.full((70, 3), 3e18, np.float32), np.full((3, 3), np.nan, np.float32), wall[500:900] + 50.0]).astype(np.float32)
+    qn = rng.normal(size=qp.shape).astype(np.float32)
+    rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, 100, 1.0)
+    want = _oracle_irr(heap, qp, qn, 100, 1.0)
+    assert _irr_equal(gscene, rgb[:500], want[:500]) and not rgb[500:].any() and not want[500:573].any()
