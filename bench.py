@@ -311,6 +311,10 @@ def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(2):
         abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), sp))
+    gs.knn_stats(True)                       # one more frame, untimed, with the kNN kernels' work counters on
+    st2 = abi.rt_stats()
+    abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st2), sp))
+    ks = gs.knn_stats(False)
     rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract + st.rays_gather
     # CPU baseline: the oracle's restatement of the same frame at 10x10 pixels, same maps
     o = ol.OracleScene(sd)
@@ -321,7 +325,10 @@ def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_
     c = o.counters()
     crays = c.rays_primary + c.rays_shadow + c.rays_reflect + c.rays_refract + c.rays_gather
     o.close(); gs.close()
-    return dict(metric="photon-mapping frame: Mrays/s and kNN radiance lookups/s", value=rays / (st.kernel_ms * 1e-3) / 1e6,
+    knn_detail = dict(waves=int(ks[6]), strict_redo_queries=int(ks[5]), waves_gave_up=int(ks[11]),
+                      walk_nodes_per_wave=float(ks[1] + ks[3]) / max(1.0, float(ks[6])),
+                      inserted_per_wave=float(ks[2]) / max(1.0, float(ks[6])), phase1_fetches_per_lookup=float(ks[0]) / max(1, st.knn_lookups))
+    return dict(metric="photon-mapping frame: Mrays/s and kNN radiance lookups/s", value=rays / (st.kernel_ms * 1e-3) / 1e6, knn=knn_detail,
                 unit="Mrays/s", lookups_per_s=st.knn_lookups / (st.kernel_ms * 1e-3), ms_per_frame=st.kernel_ms,
                 config=dict(workload=f"bundled Final scene, {res[0]}x{res[1]}, 1 AA tap, 50 gather rays, 20x20 light samples, k=100",
                             photons_global=n_global, photons_caustic=n_caustic, emissions_global=maps[0]["emissions"],

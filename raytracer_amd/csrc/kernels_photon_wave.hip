@@ -105,126 +105,99 @@ size_t w_align(size_t b) { return (b + 255) & ~(size_t)255; }
 }  // namespace
 
 
-// ---- phase 1 -----------------------------------------------------------------------------------------------------
-// out_E: the evicted photon (>= 1), -1 = the reference's heap never exists (|S| <= k), -2 = ambiguous (strict redo).
-// out_tau: the radius^2 the walk starts with.  wave_w / wave_id: per wave of 64 queries (sorted order), the largest
-// tau as its bit pattern, and the wave's number -- the (key, value) pairs of the heaviest-first order.
-__global__ void __launch_bounds__(64)
-k_irr_phase1(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3, int64_t q, int k,
-             float maxDist, const int32_t* __restrict__ perm, int32_t* __restrict__ out_E, float* __restrict__ out_tau,
-             unsigned* __restrict__ wave_w, int32_t* __restrict__ wave_id, unsigned long long* __restrict__ dbg) {
-    const int lane = threadIdx.x;
-    unsigned trips = 0;
-    const int64_t qs = (int64_t)blockIdx.x * 64 + lane;
-    const bool valid = qs < q;
-    const int64_t qi = valid ? (perm ? (int64_t)perm[qs] : qs) : 0;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (valid) { qx = pos3[3 * qi]; qy = pos3[3 * qi + 1]; qz = pos3[3 * qi + 2]; }
-    const float r0 = maxDist * maxDist;                                    // np.dist2[0], photon.cpp:405
-    const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
-    int acc = 0, E = -1;
-    float m1 = -1.f, m2 = -1.f, dN = 0.f;
-    if (valid && n >= 1) {
-        unsigned i = 1, child = 0;
-        bool up = false;
-        for (;;) {
-            const float4 rec = *reinterpret_cast<const float4*>(ph + i);
-            ++trips;
-            if (i < uhalf) {
-                const float delta = w_delta(rec, qx, qy, qz);
-                const unsigned near = (delta > 0.0f) ? 2 * i + 1 : 2 * i;
-                if (!up) { i = near; continue; }
-                if (child == near && delta * delta < r0) { i = near ^ 1u; up = false; continue; }
-            }
-            const float d2 = w_dist2(rec, qx, qy, qz);                     // both subtrees done: the node itself
-            if (d2 < r0) {
-                ++acc;
-                if (acc > k) { dN = d2; break; }
-                if (d2 > m1) { m2 = m1; m1 = d2; E = (int)i; }
-                else if (d2 > m2) m2 = d2;
-            }
-            if (i == 1) break;
-            child = i; i >>= 1; up = true;
-        }
-    }
-    const bool evict = acc > k;                                            // |S| >= k+1: the reference's heap exists
-    const bool ambiguous = evict && m1 == m2;                              // two candidates for E
-    const float tau = evict ? (m2 > dN ? m2 : dN) : r0;
-    if (valid) { out_E[qs] = ambiguous ? -2 : (evict ? E : -1); out_tau[qs] = tau; }
-    float w = (valid && !ambiguous && n >= 1) ? tau : 0.f;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(w, off, 64); w = o > w ? o : w; }
-    if (lane == 0 && wave_w) { wave_w[blockIdx.x] = (unsigned)__float_as_int(w); wave_id[blockIdx.x] = (int32_t)blockIdx.x; }
-    if (dbg) {
-        unsigned long long t = trips;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-        if (lane == 0) atomicAdd(dbg + 0, t);
-    }
-}
-
-// ---- phases 2 and 3 ------------------------------------------------------------------------------------------------
-// The walk, shared by both phases: node i at `depth`, `pending` bit d = the sibling of the path's node at depth d is
-// still to be visited.  Per lane: `fail` (W_ALIVE, or the depth at which the lane left the path: it did not want that
-// subtree) and `sib`, bit d = the lane wants the pending sibling at depth d (decided at the parent).  The records of
-// both children are fetched with the parent (32 contiguous bytes), so a descent does not wait for memory.
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+// The walk, shared by phases 2 and 3, runs on the SECOND heap (rt_internal.h: same photons, spatially ordered
+// everywhere): node i at `depth`, `pending` bit d = the sibling of the path's node at depth d is still to be visited.
+// Per lane: `fail` = W_ALIVE, or the depth at which the lane left the path (it did not want that subtree).  The
+// records of both children are fetched with the parent (32 contiguous bytes), so a descent does not wait for memory.
+// KMAX >= k + 1.
 template <int KMAX>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(64)
 k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
            const float* __restrict__ nrm3, int64_t q, int k, float maxDist, float* __restrict__ out_rgb,
            const float* __restrict__ tables, uint8_t* __restrict__ flagged, const int32_t* __restrict__ perm,
-           const int32_t* __restrict__ p1_E, const float* __restrict__ p1_tau, const int32_t* __restrict__ order,
-           unsigned budget, unsigned long long* __restrict__ dbg) {
+           unsigned budget, int group, unsigned long long* __restrict__ dbg) {
     const int lane = threadIdx.x;
     const long long t_begin = dbg ? wall_clock64() : 0;
-    const unsigned wv = order ? (unsigned)order[blockIdx.x] : blockIdx.x;  // heaviest waves first
-    const int64_t qs = (int64_t)wv * 64 + lane;                            // position in the spatially sorted order
-    const bool valid = qs < q;
+    // `group` queries per wave (64; fewer in a short launch, whose waves would otherwise be few and long: lanes >= group idle)
+    const int64_t qs = (int64_t)blockIdx.x * group + lane;                 // position in the spatially sorted order
+    const bool valid = lane < group && qs < q;
     const int64_t qi = valid ? (perm ? (int64_t)perm[qs] : qs) : 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
-    int E = -2;
-    float tau = 0.f;
-    if (valid) { qx = pos3[3 * qi]; qy = pos3[3 * qi + 1]; qz = pos3[3 * qi + 2]; E = p1_E[qs]; tau = p1_tau[qs]; }
-    const float r0 = maxDist * maxDist;
-    const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
+    if (valid) { qx = pos3[3 * qi]; qy = pos3[3 * qi + 1]; qz = pos3[3 * qi + 2]; }
+    const DevPhotonPos* __restrict__ pp = ph + 2 * (n + 1);                // second heap: positions [n+2], powers [n+1]
+    const DevPhotonPow* __restrict__ pq = reinterpret_cast<const DevPhotonPow*>(pp + (n + 2));
+    const unsigned un = (unsigned)n;
+    const float r0 = maxDist * maxDist;                                    // np.dist2[0], photon.cpp:405
     const int INF_BITS = 0x7f800000;
-    bool ambiguous = valid && E == -2;
-    const bool evict = E >= 0;
-    const bool live = valid && n >= 1 && !ambiguous;
-    unsigned d_v2 = 0, d_c2 = 0, d_v3 = 0, d_m3 = 0, d_lanes = 0;          // measurement (dbg != NULL)
+    const bool live = valid && n >= 1;
+    bool ambiguous = false;
+    unsigned d_p1 = 0, d_v2 = 0, d_c2 = 0, d_v3 = 0, d_m3 = 0, d_lanes = 0;  // measurement (dbg != NULL)
 
-    // ---- phase 2: k smallest dist2 of S \ {E} per lane ---------------------------------------------------------
+    // ---- phase 2: the k+1 smallest dist2 of S per lane ---------------------------------------------------------
     int reg[KMAX];                                                         // bit patterns of dist2, ascending
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) reg[s] = (s < KMAX - k) ? (int)0xff800000 : INF_BITS;   // the k-th smallest is always reg[KMAX-1]
+    for (int s = 0; s < KMAX; ++s) reg[s] = (s < KMAX - (k + 1)) ? (int)0xff800000 : INF_BITS;   // (k+1)-th smallest: reg[KMAX-1]
     int cnt = 0;
+    float tau = r0;
+    // a first radius per lane, so that no lane asks for the whole heap while its list is still empty: descend to the
+    // query's leaf, take the smallest sub-heap around it with at least k+1 photons the reference can reach (at most 4
+    // cannot, Q8) and the largest dist2 in it -- the (k+1)-th nearest photon is no farther
+    if (live) {
+        unsigned leaf = 1;
+        while (2 * leaf <= un) {
+            const float4 rec = *reinterpret_cast<const float4*>(pp + leaf);
+            leaf = 2 * leaf + ((w_delta(rec, qx, qy, qz) > 0.0f && 2 * leaf + 1 <= un) ? 1u : 0u);
+        }
+        unsigned root = leaf, levels = 1, have = 1;
+        while (have < (unsigned)k + 5u && root > 1) {                      // nodes of the sub-heap of `root`, `levels` deep, that exist
+            root >>= 1; ++levels;
+            have = 0;
+            for (unsigned j = 0; j < levels; ++j) {
+                const unsigned first = root << j, last = first + (1u << j) - 1u;
+                if (first <= un) have += (last <= un ? last : un) - first + 1u;
+            }
+        }
+        if (have >= (unsigned)k + 5u) {
+            float far = 0.f;
+            for (unsigned j = 0; j < levels; ++j) {
+                const unsigned first = root << j;
+                for (unsigned t = 0; t < (1u << j) && first + t <= un; ++t) {
+                    const float d2 = w_dist2(*reinterpret_cast<const float4*>(pp + first + t), qx, qy, qz);
+                    far = d2 > far ? d2 : far;                             // NaN never wins: far stays a bound of the others
+                }
+            }
+            if (far == far) tau = far < tau ? far : tau;
+        }
+    }
     bool bailed = false;
     if (__ballot(live) != 0ull) {
         int fail = live ? W_ALIVE : W_DEAD;
         unsigned i = 1, pending = 0;
         int depth = 0;
-        float4 rec = *reinterpret_cast<const float4*>(ph + 1);
+        float4 rec = *reinterpret_cast<const float4*>(pp + 1);
         for (;;) {
-            const bool internal = i < uhalf;
+            const bool internal = 2 * i <= un;
             float4 cl = rec, cr = rec;
-            if (internal) { cl = *reinterpret_cast<const float4*>(ph + 2 * i); cr = *reinterpret_cast<const float4*>(ph + 2 * i + 1); }
+            if (internal) { cl = *reinterpret_cast<const float4*>(pp + 2 * i); cr = *reinterpret_cast<const float4*>(pp + 2 * i + 1); }
             const bool al = fail == W_ALIVE;
             const float d2 = w_dist2(rec, qx, qy, qz);
-            const bool cand = al && d2 <= tau && d2 < r0 && (int)i != E;
+            const bool cand = al && d2 <= tau && d2 < r0 && !(__float_as_int(rec.w) & (int)RT_PH_UNREACHABLE);
             if (++d_v2 > budget) { bailed = true; break; }
             if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
             if (__ballot(cand) != 0ull) {
                 ++d_c2;
                 cnt += cand ? 1 : 0;
                 w_insert<KMAX>(reg, cand ? __float_as_int(d2) : INF_BITS);
-                const float kth = __int_as_float(reg[KMAX - 1]);
-                tau = tau < kth ? tau : kth;
+                const float far = __int_as_float(reg[KMAX - 1]);
+                tau = tau < far ? tau : far;
             }
             bool descended = false;
             if (internal) {
+                const bool has_r = 2 * i + 1 <= un;
                 const float delta = w_delta(rec, qx, qy, qz);
                 const bool within = delta * delta <= tau;
-                const bool wr = al && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
+                const bool wr = al && has_r && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
                 const unsigned long long wantR = __ballot(wr), wantL = __ballot(wl);
                 if ((wantL | wantR) != 0ull) {
                     const bool both = wantL != 0ull && wantR != 0ull;
@@ -246,7 +219,7 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 i ^= 1u;
                 if (fail >= depth) fail = W_ALIVE;
                 {   // does the lane want this sibling?  decided with the radius it has NOW (smaller than at the parent's visit)
-                    const float4 prec = *reinterpret_cast<const float4*>(ph + (i >> 1));
+                    const float4 prec = *reinterpret_cast<const float4*>(pp + (i >> 1));
                     const float dp = w_delta(prec, qx, qy, qz);
                     const bool want = (i & 1u) ? (dp > 0.0f || dp * dp <= tau) : (!(dp > 0.0f) || dp * dp <= tau);
                     if (fail == W_ALIVE && !want) fail = depth;
@@ -254,57 +227,97 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 if (__ballot(fail == W_ALIVE) != 0ull) break;
             }
             if (done) break;
-            rec = *reinterpret_cast<const float4*>(ph + i);
+            rec = *reinterpret_cast<const float4*>(pp + i);
         }
     }
-
-    // a wave whose walk does not end (queries that are not neighbours after all, or a part of the reference's heap that
-    // its stale bounding box left without spatial order) gives up and leaves its queries to the strict kernel, which
-    // spreads them over 16 waves: bounds the longest wave, which is what the launch waits for
+    // a wave whose walk does not end (64 queries that are not neighbours after all) gives up and leaves its queries to
+    // the strict kernel: bounds the longest wave, which is what the launch waits for
     if (bailed && live) ambiguous = true;
+#ifdef RT_KNN_TRACE_BAIL
+    if (dbg && bailed) {
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(dbg + 13, 1ull);
+        first = __shfl(first, 0, 64);
+        if ((first == 5 || first == 200) && live)
+            printf("bail lane %d q=(%.5f %.5f %.5f) tau=%.3g cnt=%d r0=%.3g k1th=%.3g n=%lld\n", lane, qx, qy, qz, tau, cnt, r0,
+                   __int_as_float(reg[KMAX - 1]), (long long)n);
+    }
+#endif
+    const float kth = __int_as_float(reg[KMAX - 2]), k1th = __int_as_float(reg[KMAX - 1]);
+    const bool evict = cnt > k;                                            // |S| >= k+1: the reference's heap exists
+
+    // ---- phase 1: which photon the reference evicts.  Its own heap, its own order, its (still fixed) radius, until it
+    //      has accepted k+1 photons; only where |S| > k, so it ends after ~k accepts -------------------------------------
+    int E = -1;
+    float dE = -1.f;
+    if (live && evict && !bailed) {
+        const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
+        int acc = 0;
+        float m2 = -1.f;
+        unsigned i = 1, child = 0;
+        bool up = false;
+        for (;;) {
+            const float4 rec = *reinterpret_cast<const float4*>(ph + i);
+            ++d_p1;
+            if (i < uhalf) {
+                const float delta = w_delta(rec, qx, qy, qz);
+                const unsigned near = (delta > 0.0f) ? 2 * i + 1 : 2 * i;
+                if (!up) { i = near; continue; }
+                if (child == near && delta * delta < r0) { i = near ^ 1u; up = false; continue; }
+            }
+            const float d2 = w_dist2(rec, qx, qy, qz);                     // both subtrees done: the node itself
+            if (d2 < r0) {
+                if (++acc > k) break;
+                if (d2 > dE) { m2 = dE; dE = d2; E = (int)i; }
+                else if (d2 > m2) m2 = d2;
+            }
+            if (i == 1) break;
+            child = i; i >>= 1; up = true;
+        }
+        if (acc <= k || dE == m2) ambiguous = true;                        // (cannot happen) / two candidates for E
+    }
+    // S \ {E}: if E is one of the k nearest, the (k+1)-th nearest takes its place
     const int found = evict ? k : cnt;
-    const float T = evict ? __int_as_float(reg[KMAX - 1]) : r0;            // the reference's final np.dist2[0]
+    const float T = evict ? (dE <= kth ? k1th : kth) : r0;                 // the reference's final np.dist2[0]
 
     // ---- phase 3: members within T, their power where the photon faces the surface -----------------------------
     float r = 0.f, g = 0.f, b = 0.f;
     int members = 0;
-    const bool summing = live && !bailed && found >= 8;                             // literal 8, photon.cpp:411
+    const bool summing = live && !ambiguous && found >= 8;                 // literal 8, photon.cpp:411
     if (__ballot(summing) != 0ull) {
         float nx = 0.f, ny = 0.f, nz = 0.f;
         if (summing) { nx = nrm3[3 * qi]; ny = nrm3[3 * qi + 1]; nz = nrm3[3 * qi + 2]; }
         const float* cosT = tables; const float* sinT = tables + 256;
         const float* cosP = tables + 512; const float* sinP = tables + 768;
-        const DevPhotonPow* __restrict__ pw = reinterpret_cast<const DevPhotonPow*>(ph + (n + 1));
         int fail = summing ? W_ALIVE : W_DEAD;
         unsigned i = 1, pending = 0;
         int depth = 0;
-        float4 rec = *reinterpret_cast<const float4*>(ph + 1);
+        float4 rec = *reinterpret_cast<const float4*>(pp + 1);
         for (;;) {
-            const bool internal = i < uhalf;
+            const bool internal = 2 * i <= un;
             float4 cl = rec, cr = rec;
-            if (internal) { cl = *reinterpret_cast<const float4*>(ph + 2 * i); cr = *reinterpret_cast<const float4*>(ph + 2 * i + 1); }
+            if (internal) { cl = *reinterpret_cast<const float4*>(pp + 2 * i); cr = *reinterpret_cast<const float4*>(pp + 2 * i + 1); }
             const bool al = fail == W_ALIVE;
             const float d2 = w_dist2(rec, qx, qy, qz);
-            const bool member = al && d2 <= T && d2 < r0 && (int)i != E;
+            const unsigned pk = (unsigned)__float_as_int(rec.w);
+            bool member = al && d2 <= T && d2 < r0 && !(pk & RT_PH_UNREACHABLE);
             ++d_v3;
             if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
             if (__ballot(member) != 0ull) {
                 ++d_m3;
+                const float4 w4 = *reinterpret_cast<const float4*>(pq + i);            // power + the reference's slot
+                member = member && __float_as_int(w4.w) != E;
                 members += member ? 1 : 0;
-                const unsigned pk = (unsigned)__float_as_int(rec.w);
                 const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
                 const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
-                const bool facing = member && (dx * nx + dy * ny + dz * nz) < 0.0f;
-                if (__ballot(facing) != 0ull) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(pw + i);
-                    if (facing) { r += w4.x; g += w4.y; b += w4.z; }
-                }
+                if (member && (dx * nx + dy * ny + dz * nz) < 0.0f) { r += w4.x; g += w4.y; b += w4.z; }
             }
             bool descended = false;
             if (internal) {
+                const bool has_r = 2 * i + 1 <= un;
                 const float delta = w_delta(rec, qx, qy, qz);
                 const bool within = delta * delta <= T;
-                const bool wr = al && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
+                const bool wr = al && has_r && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
                 const unsigned long long wantR = __ballot(wr), wantL = __ballot(wl);
                 if ((wantL | wantR) != 0ull) {
                     const bool both = wantL != 0ull && wantR != 0ull;
@@ -324,8 +337,8 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 pending &= ~(1u << depth);
                 i ^= 1u;
                 if (fail >= depth) fail = W_ALIVE;
-                {   // does the lane want this sibling?  decided with the radius it has NOW (smaller than at the parent's visit)
-                    const float4 prec = *reinterpret_cast<const float4*>(ph + (i >> 1));
+                {
+                    const float4 prec = *reinterpret_cast<const float4*>(pp + (i >> 1));
                     const float dp = w_delta(prec, qx, qy, qz);
                     const bool want = (i & 1u) ? (dp > 0.0f || dp * dp <= T) : (!(dp > 0.0f) || dp * dp <= T);
                     if (fail == W_ALIVE && !want) fail = depth;
@@ -333,15 +346,19 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 if (__ballot(fail == W_ALIVE) != 0ull) break;
             }
             if (done) break;
-            rec = *reinterpret_cast<const float4*>(ph + i);
+            rec = *reinterpret_cast<const float4*>(pp + i);
         }
-        if (summing && evict && members != k) ambiguous = true;            // more than k photons within T: a tie
+        if (summing && members != found) ambiguous = true;                 // more (or fewer) photons within T than k: a tie
         const float tmp = (float)(((double)1.0f / 3.141592) / (double)T);  // (1.0f/PI)/(np.dist2[0])
         r *= tmp; g *= tmp; b *= tmp;
     }
     if (dbg) {
         const unsigned long long fl = __popcll(__ballot(valid && ambiguous));
+        unsigned long long p1 = d_p1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) p1 += __shfl_xor(p1, off, 64);
         if (lane == 0) {
+            atomicAdd(dbg + 0, p1);
             atomicAdd(dbg + 1, (unsigned long long)d_v2); atomicAdd(dbg + 2, (unsigned long long)d_c2);
             atomicAdd(dbg + 3, (unsigned long long)d_v3); atomicAdd(dbg + 4, (unsigned long long)d_m3); atomicAdd(dbg + 5, fl);
             atomicAdd(dbg + 6, 1ull);
@@ -363,36 +380,29 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
 
 namespace {
 struct WaveWork {            // carved from the caller's workspace
-    unsigned *keys_in, *keys_out; int32_t *vals_in, *vals_out; int32_t* p1_E; float* p1_tau;
-    unsigned *wk_in, *wk_out; int32_t *wv_in, *wv_out; void* temp; size_t temp_bytes, total;
+    unsigned *keys_in, *keys_out; int32_t *vals_in, *vals_out; void* temp; size_t temp_bytes, total;
 };
 WaveWork carve(void* base, int64_t q) {
     WaveWork W;
-    const int64_t nw = (q + 63) / 64;
-    size_t t1 = 0, t2 = 0;
+    size_t t1 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned*)nullptr, (unsigned*)nullptr, (const int32_t*)nullptr,
                                              (int32_t*)nullptr, (int)q, 0, 30, (hipStream_t)nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t2, (const unsigned*)nullptr, (unsigned*)nullptr, (const int32_t*)nullptr,
-                                                       (int32_t*)nullptr, (int)nw, 0, 32, (hipStream_t)nullptr);
     char* w = (char*)base;
     auto take = [&w](size_t bytes) { char* p = w; w += w_align(bytes); return (void*)p; };
     W.keys_in = (unsigned*)take((size_t)q * 4); W.keys_out = (unsigned*)take((size_t)q * 4);
     W.vals_in = (int32_t*)take((size_t)q * 4); W.vals_out = (int32_t*)take((size_t)q * 4);
-    W.p1_E = (int32_t*)take((size_t)q * 4); W.p1_tau = (float*)take((size_t)q * 4);
-    W.wk_in = (unsigned*)take((size_t)nw * 4); W.wk_out = (unsigned*)take((size_t)nw * 4);
-    W.wv_in = (int32_t*)take((size_t)nw * 4); W.wv_out = (int32_t*)take((size_t)nw * 4);
-    W.temp_bytes = t1 > t2 ? t1 : t2;
+    W.temp_bytes = t1;
     W.temp = take(W.temp_bytes);
     W.total = (size_t)(w - (char*)base) + 256;
     return W;
 }
 }  // namespace
 
-// workspace of rtk_photon_irr_wave for q queries (sort keys / indices, phase-1 results, wave order, the sorts' storage)
+// workspace of rtk_photon_irr_wave for q queries (sort keys / indices and the sort's own storage)
 size_t rtk_photon_irr_wave_workspace(int64_t q) { return carve(nullptr, q).total; }
 
-// k <= 128.  d_flagged: q bytes, 1 = redo this query with the strict kernel.  d_work: rtk_photon_irr_wave_workspace(q)
-// bytes.  d_stats: NULL, or 16 counters that the kernels add to (rt_scene_knn_stats):
+// k <= 127.  d_flagged: q bytes, 1 = redo this query with the strict kernel.  d_work: rtk_photon_irr_wave_workspace(q)
+// bytes.  d_stats: NULL, or 16 counters that the kernel adds to (rt_scene_knn_stats):
 //   [0] phase-1 record fetches (all lanes)   [1] phase-2 node visits (per wave)   [2] photons inserted into some list
 //   [3] phase-3 node visits   [4] photons that were a member for some lane   [5] queries flagged for the strict redo
 //   [6] waves   [7] sum of wave times, 10 ns ticks   [8] longest wave << 24 | its phase-2 visits   [9] waves > 1 ms
@@ -401,12 +411,16 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
                                int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, uint8_t* d_flagged,
                                void* d_work, unsigned long long* d_stats, hipStream_t st) {
     if (q <= 0) return hipSuccess;
-    if (k < 1 || k > 128 || !d_flagged || !d_work || q > 0x7fffffff) return hipErrorInvalidValue;
+    if (k < 1 || k > 127 || !d_flagged || !d_work || q > 0x7fffffff) return hipErrorInvalidValue;
     const WaveWork W = carve(d_work, q);
-    const unsigned grid = (unsigned)((q + 63) / 64);
-    static const bool no_sort = getenv("RT_KNN_NOSORT") != nullptr, no_order = getenv("RT_KNN_NOORDER") != nullptr;
+    // queries per wave: 64 shares most, but a launch of few waves ends when its longest walk does, and a walk is
+    // serial (~0.8 us per node when the chip is not full): short launches get narrower waves, so more and shorter ones
+    static const int group_env = getenv("RT_KNN_GROUP") ? atoi(getenv("RT_KNN_GROUP")) : 0;
+    int group = q >= 64 * 8192 ? 64 : (q >= 32 * 8192 ? 32 : (q >= 16 * 4096 ? 16 : 8));
+    if (group_env == 64 || group_env == 32 || group_env == 16 || group_env == 8) group = group_env;
+    const unsigned grid = (unsigned)((q + group - 1) / group);
+    static const bool no_sort = getenv("RT_KNN_NOSORT") != nullptr;
     const int32_t* perm = nullptr;
-    hipError_t e;
     if (q > 64 && !no_sort) {
         size_t temp = W.temp_bytes;
         WBox box;
@@ -415,29 +429,18 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
             box.lo[a] = lo; box.inv[a] = hi > lo ? 1.0f / (hi - lo) : 0.f;
         }
         hipLaunchKernelGGL(k_query_keys, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, d_pos3, q, box, W.keys_in, W.vals_in);
-        e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)q, 0, 30, st);
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)q, 0, 30, st);
         if (e != hipSuccess) return e;
         perm = W.vals_out;
     }
-    hipLaunchKernelGGL(k_irr_phase1, dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, q, k, maxDist, perm, W.p1_E, W.p1_tau,
-                       W.wk_in, W.wv_in, d_stats);
-    const int32_t* order = nullptr;
-    if (grid > 64 && !no_order) {
-        size_t temp = W.temp_bytes;
-        e = hipcub::DeviceRadixSort::SortPairsDescending(W.temp, temp, W.wk_in, W.wk_out, W.wv_in, W.wv_out, (int)grid, 0, 32, st);
-        if (e != hipSuccess) return e;
-        order = W.wv_out;
-    }
-    // phase-2 node visits a wave may spend before it gives up (the mean is 1 000 - 3 000 at k = 100).  A wave alone on
-    // the chip walks at memory latency, ~0.8 us per visit: the budget is what the end of the launch can wait for, so a
-    // short launch gets a short one.
-    const unsigned budget = (unsigned)std::min<int64_t>(std::max<int64_t>((int64_t)grid / 2, 2048), 16384);
-    unsigned long long* dbg = d_stats;
-#define WAVE_ARGS dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_flagged, perm, \
-                  W.p1_E, W.p1_tau, order, budget, dbg
-    if (k <= 32) hipLaunchKernelGGL(k_irr_main<32>, WAVE_ARGS);
-    else if (k <= 64) hipLaunchKernelGGL(k_irr_main<64>, WAVE_ARGS);
-    else if (k <= 104) hipLaunchKernelGGL(k_irr_main<104>, WAVE_ARGS);
+    // phase-2 node visits a wave may spend before it gives up (the mean is 1 000 - 2 000 at k = 100): the launch
+    // ends when its longest wave does, and the strict kernel spreads the 64 queries over 16 waves.
+    static const unsigned budget_env = getenv("RT_KNN_BUDGET") ? (unsigned)atoi(getenv("RT_KNN_BUDGET")) : 0u;
+    const unsigned budget = budget_env ? budget_env : 16384u;
+#define WAVE_ARGS dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_flagged, perm, budget, group, d_stats
+    if (k <= 31) hipLaunchKernelGGL(k_irr_main<32>, WAVE_ARGS);
+    else if (k <= 63) hipLaunchKernelGGL(k_irr_main<64>, WAVE_ARGS);
+    else if (k <= 103) hipLaunchKernelGGL(k_irr_main<104>, WAVE_ARGS);
     else hipLaunchKernelGGL(k_irr_main<128>, WAVE_ARGS);
 #undef WAVE_ARGS
     return hipGetLastError();

@@ -40,8 +40,12 @@ int check_map(rt_scene* s, int which, int k, const char* fn) {
 int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
     PhotonMapDev& m = s->pmap[which];
     if (m.d_photons) { (void)hipFree(m.d_photons); m.d_photons = nullptr; m.n = 0; }
-    std::vector<DevPhotonPos> dev;                  // [n+1] positions, then [n+1] powers (same record size)
-    try { dev.resize(2 * ((size_t)n + 1)); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
+    std::vector<DevPhotonPos> dev;                  // [n+1] positions, [n+1] powers; second heap: [n+2] positions, [n+1] powers
+    std::vector<int32_t> src; std::vector<int8_t> pplane;
+    try {
+        dev.resize(4 * ((size_t)n + 1) + 1);
+        rt_photon_product_order(heap, n, src, pplane);
+    } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
     memset(dev.data(), 0, sizeof(DevPhotonPos));
     DevPhotonPow* pw = reinterpret_cast<DevPhotonPow*>(dev.data() + (size_t)n + 1);
     memset(pw, 0, sizeof(DevPhotonPow));
@@ -54,6 +58,20 @@ int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
         memcpy(d.pos, p.position, 12); memcpy(pw[i].power, p.power, 12);
         d.packed = ((uint32_t)p.plane & 3u) | ((uint32_t)p.theta << 8) | ((uint32_t)p.phi << 16);
         pw[i].pad = 0;
+    }
+    {   // the second heap: same photons, spatially ordered everywhere
+        DevPhotonPos* pp = dev.data() + 2 * ((size_t)n + 1);
+        DevPhotonPow* pq = reinterpret_cast<DevPhotonPow*>(pp + (size_t)n + 2);
+        memset(pp, 0, sizeof(DevPhotonPos)); memset(pp + (size_t)n + 1, 0, sizeof(DevPhotonPos)); memset(pq, 0, sizeof(DevPhotonPow));
+        const int64_t half = n / 2 - 1;
+        for (int64_t j = 1; j <= n; ++j) {
+            const int64_t r = src[(size_t)j];
+            const rt_photon& p = heap[r];
+            const bool reachable = r == 1 || (r >> 1) < half;          // photon.cpp:58: children only below half_stored_photons
+            memcpy(pp[j].pos, p.position, 12); memcpy(pq[j].power, p.power, 12);
+            pp[j].packed = ((uint32_t)pplane[(size_t)j] & 3u) | (reachable ? 0u : RT_PH_UNREACHABLE) | ((uint32_t)p.theta << 8) | ((uint32_t)p.phi << 16);
+            pq[j].pad = (uint32_t)r;
+        }
     }
     hipError_t e = hipMalloc((void**)&m.d_photons, dev.size() * sizeof(DevPhotonPos));
     if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(photon map %zu B): %s", dev.size() * sizeof(DevPhotonPos), hipGetErrorString(e));

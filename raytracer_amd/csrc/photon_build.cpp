@@ -37,6 +37,7 @@ struct Balancer {
     int32_t* bal;                   // pbal: heap slot -> source index
     int8_t* plane;                  // by source index
     int64_t par_min;                // segments at least this long get a thread for one half
+    bool tight;                     // second heap: split on the axis of the segment's ACTUAL largest extent
 
     // median_split, photon.cpp:224-254
     void split(int64_t start, int64_t end, int64_t median, int axis) const {
@@ -64,6 +65,15 @@ struct Balancer {
         if (3 * median <= count) { median += median; median += start - 1; }
         else median = end - median + 1;
 
+        if (tight) {
+            for (int k = 0; k < 3; ++k) { bb.lo[k] = 1e30f; bb.hi[k] = -1e30f; }
+            for (int64_t i = start; i <= end; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    const float v = org[i].p[k];
+                    if (v < bb.lo[k]) bb.lo[k] = v;
+                    if (v > bb.hi[k]) bb.hi[k] = v;
+                }
+        }
         int axis = 2;
         const float ex = bb.hi[0] - bb.lo[0], ey = bb.hi[1] - bb.lo[1], ez = bb.hi[2] - bb.lo[2];
         if (ex > ey && ex > ez) axis = 0;
@@ -109,6 +119,42 @@ void parallel_ranges(int64_t n, int nthreads, F f) {
 
 }  // namespace
 
+// The order of a SECOND heap over the same photons, for the wave-shared radiance estimate: the same
+// balancing algorithm, but every segment is split on the axis of its photons' real largest extent (the reference takes
+// the axis from a box that photon.cpp:856-859 was meant to maintain and never does).
+// With the box the reference actually uses (never filled in, Q7) the split axis stops following the data next to the
+// scene's minimum faces, and coplanar photons (a wall, the caustic floor) end up in sub-heaps without spatial order,
+// which every query there has to scan; this order has none.  src[j] = position in `heap` of the photon at slot j,
+// plane[j] = its split axis; heap[1..n] is not modified.
+void rt_photon_product_order(const rt_photon* heap, int64_t n, std::vector<int32_t>& src, std::vector<int8_t>& plane_out) {
+    src.assign((size_t)n + 2, 0);
+    plane_out.assign((size_t)n + 2, 0);
+    if (n < 1) return;
+    if (n == 1) { src[1] = 1; return; }
+    const int nt = rt_host_threads();
+    std::vector<Rec> org((size_t)n + 1);
+    std::vector<int32_t> bal((size_t)2 * n + 4, 0);
+    std::vector<int8_t> plane((size_t)n + 1, -1);
+    Box bb;
+    for (int k = 0; k < 3; ++k) { bb.lo[k] = 1e30f; bb.hi[k] = -1e30f; }
+    for (int64_t i = 0; i <= n; ++i) {
+        Rec& r = org[(size_t)i];
+        for (int k = 0; k < 3; ++k) {
+            r.p[k] = heap[i].position[k];
+            if (i >= 1 && r.p[k] > -1e30f && r.p[k] < 1e30f) { bb.lo[k] = std::min(bb.lo[k], r.p[k]); bb.hi[k] = std::max(bb.hi[k], r.p[k]); }
+        }
+        r.idx = (int32_t)i;
+    }
+    for (int k = 0; k < 3; ++k) if (!(bb.lo[k] <= bb.hi[k])) { bb.lo[k] = 0.f; bb.hi[k] = 0.f; }
+    Balancer b{org.data(), bal.data(), plane.data(), nt > 1 ? std::max<int64_t>(1 << 15, n / (4 * nt)) : INT64_MAX, true};
+    b.segment(1, 1, n, bb);
+    for (int64_t j = 1; j <= n; ++j) {
+        src[(size_t)j] = bal[(size_t)j];
+        const int8_t pl = plane[(size_t)bal[(size_t)j]];
+        plane_out[(size_t)j] = pl >= 0 ? pl : 0;
+    }
+}
+
 // photons[0] unused, photons[1..n] in storage order; on return photons[1..n] in heap order.
 void rt_photon_balance_host(rt_photon* photons, int64_t n) {
     if (n <= 1) return;                                   // photon.cpp:135
@@ -123,7 +169,7 @@ void rt_photon_balance_host(rt_photon* photons, int64_t n) {
             r.idx = (int32_t)i;
         }
     });
-    Balancer b{org.data(), bal.data(), plane.data(), nt > 1 ? std::max<int64_t>(1 << 15, n / (4 * nt)) : INT64_MAX};
+    Balancer b{org.data(), bal.data(), plane.data(), nt > 1 ? std::max<int64_t>(1 << 15, n / (4 * nt)) : INT64_MAX, false};
     Box bb;
     for (int k = 0; k < 3; ++k) { bb.lo[k] = -1e9f; bb.hi[k] = 1e9f; }
     b.segment(1, 1, n, bb);

@@ -81,10 +81,14 @@ struct DevLight {           // 64 B
 // Photon map in HBM: two arrays in the reference's 1-based heap order (slot 0 unused), back to back in one
 // allocation.  A tree visit reads only DevPhotonPos (16 B); the power array is touched once per found photon.
 // 10 M photons: 160 MB of positions (fits the 256 MB Infinity Cache) + 160 MB of powers.
-struct DevPhotonPos { float pos[3]; uint32_t packed; };    // packed: plane (bits 0..1) | theta<<8 | phi<<16
-struct DevPhotonPow { float power[3]; uint32_t pad; };
+struct DevPhotonPos { float pos[3]; uint32_t packed; };    // packed: plane (bits 0..1) | RT_PH_UNREACHABLE | theta<<8 | phi<<16
+struct DevPhotonPow { float power[3]; uint32_t pad; };     // pad: second heap only, the photon's slot in the reference's heap
 static_assert(sizeof(DevPhotonPos) == 16 && sizeof(DevPhotonPow) == 16, "photon records must be 16 bytes");
-typedef DevPhotonPos DevPhoton;   // base pointer of the allocation: [n+1] DevPhotonPos then [n+1] DevPhotonPow
+// base pointer of the allocation: [n+1] DevPhotonPos, [n+1] DevPhotonPow in the REFERENCE's heap order, then the same
+// photons again in the order of rt_photon_product_order: [n+2] DevPhotonPos (one padding record: both children are
+// fetched together), [n+1] DevPhotonPow
+typedef DevPhotonPos DevPhoton;
+#define RT_PH_UNREACHABLE 4u      // second heap: the reference's LocatePhoton never reaches this photon (Q8)
 
 struct DevSceneView {       // passed by value to kernels
     const DevNode* nodes; int32_t nnodes;      // reference order (= layout 7: right child first everywhere)
@@ -126,6 +130,7 @@ struct HostFlatScene {
 int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string* err);
 // photon_build.cpp
 void rt_photon_balance_host(rt_photon* photons, int64_t n);
+void rt_photon_product_order(const rt_photon* heap, int64_t n, std::vector<int32_t>& src, std::vector<int8_t>& plane);
 int rt_host_threads();     // threads of the host-side builders: RT_HOST_THREADS, else min(16, cores)
 
 // smallest float f such that (double)f > t   (so  (double)x > t  <=>  x >= f  for every float x)

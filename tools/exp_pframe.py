@@ -6,4 +6,4 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 r = bench.photon_frame_secondary(torch, 0)
-print(json.dumps({k: r[k] for k in ("value", "lookups_per_s", "ms_per_frame", "knn_lookups")}))
+print(json.dumps({k: r[k] for k in ("value", "lookups_per_s", "ms_per_frame", "knn_lookups", "knn")}))
