@@ -135,7 +135,7 @@ k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const fl
              const float* __restrict__ nrm3, int64_t q, int k, float maxDist, int mode,
              int32_t* __restrict__ out_idx, float* __restrict__ out_d2, int32_t* __restrict__ out_found,
              float* __restrict__ out_r2, float* __restrict__ out_rgb, const float* __restrict__ tables, int xcd_map,
-             const uint8_t* __restrict__ only) {
+             const uint8_t* __restrict__ only, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist) {
     extern __shared__ float lds[];
     KnnLds L;
     L.hd = lds;
@@ -149,42 +149,50 @@ k_photon_knn(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const fl
     // (the grid is a multiple of 8 blocks: block b -> logical block (b % 8) * (grid / 8) + b / 8, a bijection)
     const unsigned per = gridDim.x >> 3;
     const unsigned lb = xcd_map ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    const int64_t i = (int64_t)lb * KNN_QL + t;
-    if (t >= KNN_QL || i >= q) return;
-    if (only && !only[i]) return;                                  // redo pass: only the queries the fast kernel flagged
-    const float qx = pos3[3 * i], qy = pos3[3 * i + 1], qz = pos3[3 * i + 2];
-    float r2 = maxDist * maxDist;                                  // np.dist2[0], photon.cpp:405
-    int found;
-    locate<KNN_QL>(ph, n, half, L, t, k, qx, qy, qz, r2, found);
-    L.hd[t] = r2;
-    if (mode == 0) {
-        for (int j = 0; j < k; ++j) {
-            out_idx[i * k + j] = j < found ? L.hi[(j + 1) * KNN_QL + t] : -1;
-            out_d2[i * k + j] = j < found ? L.hd[(j + 1) * KNN_QL + t] : 0.0f;
-        }
-        out_found[i] = found;
-        if (out_r2) out_r2[i] = L.hd[t];
-    } else {
-        float r = 0.f, g = 0.f, b = 0.f;
-        if (found >= 8) {                                          // literal 8, photon.cpp:411
-            const float nx = nrm3[3 * i], ny = nrm3[3 * i + 1], nz = nrm3[3 * i + 2];
-            const float* cosT = tables; const float* sinT = tables + 256;
-            const float* cosP = tables + 512; const float* sinP = tables + 768;
-            const DevPhotonPow* pw = reinterpret_cast<const DevPhotonPow*>(ph + (n + 1));
-            for (int j = 1; j <= found; ++j) {
-                const int pi = L.hi[j * KNN_QL + t];
-                const unsigned pk = ph[pi].packed;
-                const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
-                const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
-                if ((dx * nx + dy * ny + dz * nz) < 0.0f) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(pw + pi);
-                    r += w4.x; g += w4.y; b += w4.z;
-                }
+    if (t >= KNN_QL) return;
+    // `list` (redo pass of the fast kernels): the queries to do are list[0 .. *nlist), ONE per wave (they are few, and
+    // a wave is as slow as its slowest query), the blocks stride over them
+    if (list && t > 0) return;
+    const int64_t stride = list ? (int64_t)gridDim.x : 0;
+    for (int64_t j = list ? (int64_t)lb : (int64_t)lb * KNN_QL + t;; j += stride) {
+        int64_t i = j;
+        if (list) { if (j >= (int64_t)*nlist) break; i = list[j]; }
+        else if (i >= q || (only && !only[i])) break;                  // `only`: the queries the cooperative kernel flagged
+        const float qx = pos3[3 * i], qy = pos3[3 * i + 1], qz = pos3[3 * i + 2];
+        float r2 = maxDist * maxDist;                                  // np.dist2[0], photon.cpp:405
+        int found;
+        locate<KNN_QL>(ph, n, half, L, t, k, qx, qy, qz, r2, found);
+        L.hd[t] = r2;
+        if (mode == 0) {
+            for (int jj = 0; jj < k; ++jj) {
+                out_idx[i * k + jj] = jj < found ? L.hi[(jj + 1) * KNN_QL + t] : -1;
+                out_d2[i * k + jj] = jj < found ? L.hd[(jj + 1) * KNN_QL + t] : 0.0f;
             }
-            const float tmp = (float)(((double)1.0f / 3.141592) / (double)L.hd[t]);   // (1.0f/PI)/(np.dist2[0])
-            r *= tmp; g *= tmp; b *= tmp;
+            out_found[i] = found;
+            if (out_r2) out_r2[i] = L.hd[t];
+        } else {
+            float r = 0.f, g = 0.f, b = 0.f;
+            if (found >= 8) {                                          // literal 8, photon.cpp:411
+                const float nx = nrm3[3 * i], ny = nrm3[3 * i + 1], nz = nrm3[3 * i + 2];
+                const float* cosT = tables; const float* sinT = tables + 256;
+                const float* cosP = tables + 512; const float* sinP = tables + 768;
+                const DevPhotonPow* pw = reinterpret_cast<const DevPhotonPow*>(ph + (n + 1));
+                for (int jj = 1; jj <= found; ++jj) {
+                    const int pi = L.hi[jj * KNN_QL + t];
+                    const unsigned pk = ph[pi].packed;
+                    const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
+                    const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
+                    if ((dx * nx + dy * ny + dz * nz) < 0.0f) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(pw + pi);
+                        r += w4.x; g += w4.y; b += w4.z;
+                    }
+                }
+                const float tmp = (float)(((double)1.0f / 3.141592) / (double)L.hd[t]);   // (1.0f/PI)/(np.dist2[0])
+                r *= tmp; g *= tmp; b *= tmp;
+            }
+            out_rgb[3 * i] = r; out_rgb[3 * i + 1] = g; out_rgb[3 * i + 2] = b;
         }
-        out_rgb[3 * i] = r; out_rgb[3 * i + 1] = g; out_rgb[3 * i + 2] = b;
+        if (!list) break;
     }
 }
 
@@ -361,15 +369,18 @@ size_t rtk_knn_lds_bytes(int k) { return (size_t)(2 * (k + 1) + 2 * KNN_LEVELS) 
 template <int QL>
 static hipError_t launch_knn(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
                              int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
-                             float* d_r2, float* d_rgb, const float* d_tables, const uint8_t* only, hipStream_t st) {
+                             float* d_r2, float* d_rgb, const float* d_tables, const uint8_t* only, hipStream_t st,
+                             const int32_t* list = nullptr, const unsigned* nlist = nullptr) {
     const size_t lds = (size_t)(2 * (k + 1) + 2 * KNN_LEVELS) * QL * 4;
     if (lds > 64 * 1024) {   // per current device; cheap enough to repeat
         hipError_t e = hipFuncSetAttribute((const void*)k_photon_knn<QL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const unsigned grid = (unsigned)((((q + QL - 1) / QL) + 7) / 8) * 8;
+    // redo pass: a fixed grid strides over the list (its length is only known on the device)
+    const unsigned grid = list ? 2048u : (unsigned)((((q + QL - 1) / QL) + 7) / 8) * 8;
     hipLaunchKernelGGL(k_photon_knn<QL>, dim3(grid), dim3(64), lds, st, ph, n, half, d_pos3, d_nrm3, q,
-                       k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, getenv("RT_KNN_XCD") ? atoi(getenv("RT_KNN_XCD")) : 0, only);
+                       k, maxDist, mode, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, list ? 0 : (getenv("RT_KNN_XCD") ? atoi(getenv("RT_KNN_XCD")) : 0), only,
+                       list, nlist);
     return hipGetLastError();
 }
 
@@ -390,7 +401,9 @@ hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const fl
 #undef KNN_ARGS
 }
 
-size_t rtk_knn_fast_scratch_bytes(int64_t q) { return (((size_t)q + 255) & ~(size_t)255) + rtk_photon_irr_wave_workspace(q); }
+size_t rtk_knn_fast_scratch_bytes(int64_t q) {
+    return (((size_t)q + 255) & ~(size_t)255) + 256 + 4 * (((size_t)q + 63) & ~(size_t)63) + rtk_photon_irr_wave_workspace(q);
+}
 
 // Fast path: wave-shared kernel (mode 1) or cooperative kernel (mode 2), then the strict kernel redoes the flagged
 // queries.  d_flagged: rtk_knn_fast_scratch_bytes(q) bytes (one flag per query, then the sort's workspace).
@@ -403,10 +416,15 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
     static const bool use_coop = getenv("RT_KNN_COOP") != nullptr;       // the 16-lane kernel for mode 1 too (experiments)
     if (mode == 1 && !use_coop) {
         // irradiance: the wave-shared kernel (kernels_photon_wave.hip), then the strict kernel redoes the flagged queries
-        void* work = (void*)(d_flagged + (((size_t)q + 255) & ~(size_t)255));
-        hipError_t e = rtk_photon_irr_wave(ph, n, half, box6, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_flagged, work, d_stats, st);
+        // the wave-shared kernel lists the queries it leaves to the strict one: [count][indices] at the head of the workspace
+        unsigned* nlist = (unsigned*)(d_flagged + (((size_t)q + 255) & ~(size_t)255));
+        int32_t* list = (int32_t*)(nlist + 64);
+        void* work = (void*)(list + (((size_t)q + 63) & ~(size_t)63));
+        hipError_t e = hipMemsetAsync(nlist, 0, 4, st);
         if (e != hipSuccess) return e;
-        return launch_knn<4>(ph, n, half, d_pos3, d_nrm3, q, k, maxDist, 1, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, d_flagged, st);
+        e = rtk_photon_irr_wave(ph, n, half, box6, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, list, nlist, work, d_stats, st);
+        if (e != hipSuccess) return e;
+        return launch_knn<4>(ph, n, half, d_pos3, d_nrm3, q, k, maxDist, 1, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, nullptr, st, list, nlist);
     }
     const unsigned grid = (unsigned)((q + 3) / 4);
     if (k <= 48)

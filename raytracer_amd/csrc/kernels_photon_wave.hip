@@ -50,6 +50,18 @@ __device__ __forceinline__ float w_delta(const float4& rec, float qx, float qy, 
     return qp - pp;                             // photon.cpp:61
 }
 
+// squared distance from the query to a box, in the operation order of w_dist2: for a photon inside the box every
+// term is <= the photon's (float subtraction, multiplication and addition are monotone), so the result is <= its dist2
+__device__ __forceinline__ float w_boxdist(const float4& lo, const float4& hi, float qx, float qy, float qz) {
+    const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi.x), 0.0f);
+    const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi.y), 0.0f);
+    const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi.z), 0.0f);
+    float d = dx * dx;
+    d += dy * dy;
+    d += dz * dz;
+    return d;
+}
+
 // sorted insertion of x into the ascending list: a chain of compare-exchanges, all in registers.  The entries are the
 // BIT PATTERNS of dist2 (>= 0, or the -inf / +inf sentinels): for those, integer order is float order, and
 // v_min_i32 / v_max_i32 need no NaN canonicalisation.  Blocks whose last entry no lane undercuts are skipped.
@@ -107,16 +119,18 @@ size_t w_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
 // The walk, shared by phases 2 and 3, runs on the SECOND heap (rt_internal.h: same photons, spatially ordered
-// everywhere): node i at `depth`, `pending` bit d = the sibling of the path's node at depth d is still to be visited.
-// Per lane: `fail` = W_ALIVE, or the depth at which the lane left the path (it did not want that subtree).  The
-// records of both children are fetched with the parent (32 contiguous bytes), so a descent does not wait for memory.
+// everywhere, with the bounding box of every sub-heap): node i at `depth`, `pending` bit d = the sibling of the path's
+// node at depth d is still to be visited.  Per lane: `fail` = W_ALIVE, or the depth at which the lane left the path
+// (it did not want that subtree: its distance to the sub-heap's box exceeds its radius -- a far tighter test than the
+// reference's single split plane, and still exact, see w_boxdist).  Children without children are tested at their
+// parent; the records and boxes of both children are fetched together (contiguous), so a descent waits for one fetch.
 // KMAX >= k + 1.
 template <int KMAX>
 __global__ void __launch_bounds__(64)
 k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
            const float* __restrict__ nrm3, int64_t q, int k, float maxDist, float* __restrict__ out_rgb,
-           const float* __restrict__ tables, uint8_t* __restrict__ flagged, const int32_t* __restrict__ perm,
-           unsigned budget, int group, unsigned long long* __restrict__ dbg) {
+           const float* __restrict__ tables, int32_t* __restrict__ redo_list, unsigned* __restrict__ redo_count,
+           const int32_t* __restrict__ perm, unsigned budget, int group, unsigned long long* __restrict__ dbg) {
     const int lane = threadIdx.x;
     const long long t_begin = dbg ? wall_clock64() : 0;
     // `group` queries per wave (64; fewer in a short launch, whose waves would otherwise be few and long: lanes >= group idle)
@@ -127,7 +141,8 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     if (valid) { qx = pos3[3 * qi]; qy = pos3[3 * qi + 1]; qz = pos3[3 * qi + 2]; }
     const DevPhotonPos* __restrict__ pp = ph + 2 * (n + 1);                // second heap: positions [n+2], powers [n+1]
     const DevPhotonPow* __restrict__ pq = reinterpret_cast<const DevPhotonPow*>(pp + (n + 2));
-    const unsigned un = (unsigned)n;
+    const float4* __restrict__ bx = reinterpret_cast<const float4*>(pq + (n + 1));   // corners 2i, 2i+1 of node i's sub-heap box
+    const unsigned un = (unsigned)n, nb = (unsigned)(n / 2);               // nodes 1..nb have a child
     const float r0 = maxDist * maxDist;                                    // np.dist2[0], photon.cpp:405
     const int INF_BITS = 0x7f800000;
     const bool live = valid && n >= 1;
@@ -172,19 +187,9 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     }
     bool bailed = false;
     if (__ballot(live) != 0ull) {
-        int fail = live ? W_ALIVE : W_DEAD;
-        unsigned i = 1, pending = 0;
-        int depth = 0;
-        float4 rec = *reinterpret_cast<const float4*>(pp + 1);
-        for (;;) {
-            const bool internal = 2 * i <= un;
-            float4 cl = rec, cr = rec;
-            if (internal) { cl = *reinterpret_cast<const float4*>(pp + 2 * i); cr = *reinterpret_cast<const float4*>(pp + 2 * i + 1); }
-            const bool al = fail == W_ALIVE;
-            const float d2 = w_dist2(rec, qx, qy, qz);
-            const bool cand = al && d2 <= tau && d2 < r0 && !(__float_as_int(rec.w) & (int)RT_PH_UNREACHABLE);
-            if (++d_v2 > budget) { bailed = true; break; }
-            if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
+        auto visit = [&](const float4& r4, bool al) {                      // one photon, every lane that is in its subtree
+            const float d2 = w_dist2(r4, qx, qy, qz);
+            const bool cand = al && d2 <= tau && d2 < r0 && !(__float_as_int(r4.w) & (int)RT_PH_UNREACHABLE);
             if (__ballot(cand) != 0ull) {
                 ++d_c2;
                 cnt += cand ? 1 : 0;
@@ -192,22 +197,42 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 const float far = __int_as_float(reg[KMAX - 1]);
                 tau = tau < far ? tau : far;
             }
+        };
+        int fail = live ? W_ALIVE : W_DEAD;
+        unsigned i = 1, pending = 0;
+        int depth = 0;
+        float4 rec = *reinterpret_cast<const float4*>(pp + 1);
+        for (;;) {
+            const bool al = fail == W_ALIVE;
+            if (++d_v2 > budget) { bailed = true; break; }
+            if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
+            visit(rec, al);
             bool descended = false;
-            if (internal) {
-                const bool has_r = 2 * i + 1 <= un;
-                const float delta = w_delta(rec, qx, qy, qz);
-                const bool within = delta * delta <= tau;
-                const bool wr = al && has_r && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
-                const unsigned long long wantR = __ballot(wr), wantL = __ballot(wl);
-                if ((wantL | wantR) != 0ull) {
-                    const bool both = wantL != 0ull && wantR != 0ull;
-                    // the side most lanes are on first: the lists fill with close photons early and tau shrinks
-                    const bool right_first = both ? 2 * __popcll(__ballot(al && delta > 0.0f)) > __popcll(__ballot(al)) : wantR != 0ull;
-                    ++depth;
-                    if (both) pending |= 1u << depth;
-                    if (al && !(right_first ? wr : wl)) fail = depth;
-                    rec = right_first ? cr : cl; i = 2 * i + (right_first ? 1u : 0u);
-                    descended = true;
+            const unsigned c0 = 2 * i;
+            if (c0 <= un) {
+                const bool has_r = c0 + 1 <= un;
+                const float4 cl = *reinterpret_cast<const float4*>(pp + c0), cr = *reinterpret_cast<const float4*>(pp + c0 + 1);
+                if (c0 > nb) {                                             // the children have none: test them here
+                    visit(cl, al);
+                    if (has_r) visit(cr, al);
+                } else {
+                    const float4 l0 = bx[2 * c0], h0 = bx[2 * c0 + 1];
+                    const bool w0 = al && w_boxdist(l0, h0, qx, qy, qz) <= tau;
+                    bool w1 = false;
+                    if (c0 + 1 <= nb) { const float4 l1 = bx[2 * c0 + 2], h1 = bx[2 * c0 + 3]; w1 = al && w_boxdist(l1, h1, qx, qy, qz) <= tau; }
+                    else if (has_r) w1 = al && w_dist2(cr, qx, qy, qz) <= tau;
+                    const unsigned long long wantL = __ballot(w0), wantR = __ballot(w1);
+                    if ((wantL | wantR) != 0ull) {
+                        const bool both = wantL != 0ull && wantR != 0ull;
+                        // the side most lanes are on first: the lists fill with close photons early and tau shrinks
+                        const bool right_first = both ? 2 * __popcll(__ballot(al && w_delta(rec, qx, qy, qz) > 0.0f)) > __popcll(__ballot(al))
+                                                      : wantR != 0ull;
+                        ++depth;
+                        if (both) pending |= 1u << depth;
+                        if (al && !(right_first ? w1 : w0)) fail = depth;
+                        rec = right_first ? cr : cl; i = c0 + (right_first ? 1u : 0u);
+                        descended = true;
+                    }
                 }
             }
             if (descended) continue;
@@ -218,16 +243,13 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 pending &= ~(1u << depth);
                 i ^= 1u;
                 if (fail >= depth) fail = W_ALIVE;
-                {   // does the lane want this sibling?  decided with the radius it has NOW (smaller than at the parent's visit)
-                    const float4 prec = *reinterpret_cast<const float4*>(pp + (i >> 1));
-                    const float dp = w_delta(prec, qx, qy, qz);
-                    const bool want = (i & 1u) ? (dp > 0.0f || dp * dp <= tau) : (!(dp > 0.0f) || dp * dp <= tau);
-                    if (fail == W_ALIVE && !want) fail = depth;
-                }
+                rec = *reinterpret_cast<const float4*>(pp + i);
+                // does the lane want this sibling?  decided with the radius it has NOW (smaller than at the parent's visit)
+                const bool want = (i <= nb ? w_boxdist(bx[2 * i], bx[2 * i + 1], qx, qy, qz) : w_dist2(rec, qx, qy, qz)) <= tau;
+                if (fail == W_ALIVE && !want) fail = depth;
                 if (__ballot(fail == W_ALIVE) != 0ull) break;
             }
             if (done) break;
-            rec = *reinterpret_cast<const float4*>(pp + i);
         }
     }
     // a wave whose walk does not end (64 queries that are not neighbours after all) gives up and leaves its queries to
@@ -289,44 +311,53 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
         if (summing) { nx = nrm3[3 * qi]; ny = nrm3[3 * qi + 1]; nz = nrm3[3 * qi + 2]; }
         const float* cosT = tables; const float* sinT = tables + 256;
         const float* cosP = tables + 512; const float* sinP = tables + 768;
-        int fail = summing ? W_ALIVE : W_DEAD;
-        unsigned i = 1, pending = 0;
-        int depth = 0;
-        float4 rec = *reinterpret_cast<const float4*>(pp + 1);
-        for (;;) {
-            const bool internal = 2 * i <= un;
-            float4 cl = rec, cr = rec;
-            if (internal) { cl = *reinterpret_cast<const float4*>(pp + 2 * i); cr = *reinterpret_cast<const float4*>(pp + 2 * i + 1); }
-            const bool al = fail == W_ALIVE;
-            const float d2 = w_dist2(rec, qx, qy, qz);
-            const unsigned pk = (unsigned)__float_as_int(rec.w);
+        auto visit = [&](const float4& r4, unsigned idx, bool al) {
+            const float d2 = w_dist2(r4, qx, qy, qz);
+            const unsigned pk = (unsigned)__float_as_int(r4.w);
             bool member = al && d2 <= T && d2 < r0 && !(pk & RT_PH_UNREACHABLE);
-            ++d_v3;
-            if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
             if (__ballot(member) != 0ull) {
                 ++d_m3;
-                const float4 w4 = *reinterpret_cast<const float4*>(pq + i);            // power + the reference's slot
+                const float4 w4 = *reinterpret_cast<const float4*>(pq + idx);          // power + the reference's slot
                 member = member && __float_as_int(w4.w) != E;
                 members += member ? 1 : 0;
                 const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
                 const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
                 if (member && (dx * nx + dy * ny + dz * nz) < 0.0f) { r += w4.x; g += w4.y; b += w4.z; }
             }
+        };
+        int fail = summing ? W_ALIVE : W_DEAD;
+        unsigned i = 1, pending = 0;
+        int depth = 0;
+        float4 rec = *reinterpret_cast<const float4*>(pp + 1);
+        for (;;) {
+            const bool al = fail == W_ALIVE;
+            ++d_v3;
+            if (dbg) d_lanes += (unsigned)__popcll(__ballot(al));
+            visit(rec, i, al);
             bool descended = false;
-            if (internal) {
-                const bool has_r = 2 * i + 1 <= un;
-                const float delta = w_delta(rec, qx, qy, qz);
-                const bool within = delta * delta <= T;
-                const bool wr = al && has_r && (delta > 0.0f || within), wl = al && (!(delta > 0.0f) || within);
-                const unsigned long long wantR = __ballot(wr), wantL = __ballot(wl);
-                if ((wantL | wantR) != 0ull) {
-                    const bool both = wantL != 0ull && wantR != 0ull;
-                    const bool right_first = both ? false : wantR != 0ull;
-                    ++depth;
-                    if (both) pending |= 1u << depth;
-                    if (al && !(right_first ? wr : wl)) fail = depth;
-                    rec = right_first ? cr : cl; i = 2 * i + (right_first ? 1u : 0u);
-                    descended = true;
+            const unsigned c0 = 2 * i;
+            if (c0 <= un) {
+                const bool has_r = c0 + 1 <= un;
+                const float4 cl = *reinterpret_cast<const float4*>(pp + c0), cr = *reinterpret_cast<const float4*>(pp + c0 + 1);
+                if (c0 > nb) {
+                    visit(cl, c0, al);
+                    if (has_r) visit(cr, c0 + 1, al);
+                } else {
+                    const float4 l0 = bx[2 * c0], h0 = bx[2 * c0 + 1];
+                    const bool w0 = al && w_boxdist(l0, h0, qx, qy, qz) <= T;
+                    bool w1 = false;
+                    if (c0 + 1 <= nb) { const float4 l1 = bx[2 * c0 + 2], h1 = bx[2 * c0 + 3]; w1 = al && w_boxdist(l1, h1, qx, qy, qz) <= T; }
+                    else if (has_r) w1 = al && w_dist2(cr, qx, qy, qz) <= T;
+                    const unsigned long long wantL = __ballot(w0), wantR = __ballot(w1);
+                    if ((wantL | wantR) != 0ull) {
+                        const bool both = wantL != 0ull && wantR != 0ull;
+                        const bool right_first = both ? false : wantR != 0ull;
+                        ++depth;
+                        if (both) pending |= 1u << depth;
+                        if (al && !(right_first ? w1 : w0)) fail = depth;
+                        rec = right_first ? cr : cl; i = c0 + (right_first ? 1u : 0u);
+                        descended = true;
+                    }
                 }
             }
             if (descended) continue;
@@ -337,16 +368,12 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 pending &= ~(1u << depth);
                 i ^= 1u;
                 if (fail >= depth) fail = W_ALIVE;
-                {
-                    const float4 prec = *reinterpret_cast<const float4*>(pp + (i >> 1));
-                    const float dp = w_delta(prec, qx, qy, qz);
-                    const bool want = (i & 1u) ? (dp > 0.0f || dp * dp <= T) : (!(dp > 0.0f) || dp * dp <= T);
-                    if (fail == W_ALIVE && !want) fail = depth;
-                }
+                rec = *reinterpret_cast<const float4*>(pp + i);
+                const bool want = (i <= nb ? w_boxdist(bx[2 * i], bx[2 * i + 1], qx, qy, qz) : w_dist2(rec, qx, qy, qz)) <= T;
+                if (fail == W_ALIVE && !want) fail = depth;
                 if (__ballot(fail == W_ALIVE) != 0ull) break;
             }
             if (done) break;
-            rec = *reinterpret_cast<const float4*>(pp + i);
         }
         if (summing && members != found) ambiguous = true;                 // more (or fewer) photons within T than k: a tie
         const float tmp = (float)(((double)1.0f / 3.141592) / (double)T);  // (1.0f/PI)/(np.dist2[0])
@@ -374,7 +401,7 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     if (valid) {
         if (ambiguous) { r = 0.f; g = 0.f; b = 0.f; }
         out_rgb[3 * qi] = r; out_rgb[3 * qi + 1] = g; out_rgb[3 * qi + 2] = b;
-        flagged[qi] = ambiguous ? 1 : 0;
+        if (ambiguous) redo_list[atomicAdd(redo_count, 1u)] = (int32_t)qi;             // rare: exact ties, give-ups
     }
 }
 
@@ -401,17 +428,17 @@ WaveWork carve(void* base, int64_t q) {
 // workspace of rtk_photon_irr_wave for q queries (sort keys / indices and the sort's own storage)
 size_t rtk_photon_irr_wave_workspace(int64_t q) { return carve(nullptr, q).total; }
 
-// k <= 127.  d_flagged: q bytes, 1 = redo this query with the strict kernel.  d_work: rtk_photon_irr_wave_workspace(q)
-// bytes.  d_stats: NULL, or 16 counters that the kernel adds to (rt_scene_knn_stats):
+// k <= 127.  d_redo_list [q] / d_redo_count (zeroed by the caller): the queries left to the strict kernel.  d_work:
+// rtk_photon_irr_wave_workspace(q) bytes.  d_stats: NULL, or 16 counters that the kernel adds to (rt_scene_knn_stats):
 //   [0] phase-1 record fetches (all lanes)   [1] phase-2 node visits (per wave)   [2] photons inserted into some list
 //   [3] phase-3 node visits   [4] photons that were a member for some lane   [5] queries flagged for the strict redo
 //   [6] waves   [7] sum of wave times, 10 ns ticks   [8] longest wave << 24 | its phase-2 visits   [9] waves > 1 ms
 //   [10] waves > 10 ms   [11] waves that gave up   [12] node visits summed over the lanes that were in the subtree
 hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, const float* d_pos3, const float* d_nrm3,
-                               int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, uint8_t* d_flagged,
-                               void* d_work, unsigned long long* d_stats, hipStream_t st) {
+                               int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, int32_t* d_redo_list,
+                               unsigned* d_redo_count, void* d_work, unsigned long long* d_stats, hipStream_t st) {
     if (q <= 0) return hipSuccess;
-    if (k < 1 || k > 127 || !d_flagged || !d_work || q > 0x7fffffff) return hipErrorInvalidValue;
+    if (k < 1 || k > 127 || !d_redo_list || !d_redo_count || !d_work || q > 0x7fffffff) return hipErrorInvalidValue;
     const WaveWork W = carve(d_work, q);
     // queries per wave: 64 shares most, but a launch of few waves ends when its longest walk does, and a walk is
     // serial (~0.8 us per node when the chip is not full): short launches get narrower waves, so more and shorter ones
@@ -437,7 +464,7 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
     // ends when its longest wave does, and the strict kernel spreads the 64 queries over 16 waves.
     static const unsigned budget_env = getenv("RT_KNN_BUDGET") ? (unsigned)atoi(getenv("RT_KNN_BUDGET")) : 0u;
     const unsigned budget = budget_env ? budget_env : 16384u;
-#define WAVE_ARGS dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_flagged, perm, budget, group, d_stats
+#define WAVE_ARGS dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_redo_list, d_redo_count, perm, budget, group, d_stats
     if (k <= 31) hipLaunchKernelGGL(k_irr_main<32>, WAVE_ARGS);
     else if (k <= 63) hipLaunchKernelGGL(k_irr_main<64>, WAVE_ARGS);
     else if (k <= 103) hipLaunchKernelGGL(k_irr_main<104>, WAVE_ARGS);

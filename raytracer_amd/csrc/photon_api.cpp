@@ -40,10 +40,11 @@ int check_map(rt_scene* s, int which, int k, const char* fn) {
 int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
     PhotonMapDev& m = s->pmap[which];
     if (m.d_photons) { (void)hipFree(m.d_photons); m.d_photons = nullptr; m.n = 0; }
-    std::vector<DevPhotonPos> dev;                  // [n+1] positions, [n+1] powers; second heap: [n+2] positions, [n+1] powers
-    std::vector<int32_t> src; std::vector<int8_t> pplane;
+    std::vector<DevPhotonPos> dev;                  // [n+1] positions, [n+1] powers; second heap: [n+2] positions, [n+1] powers,
+    std::vector<int32_t> src; std::vector<int8_t> pplane;   // [2 (n/2 + 2)] box corners
+    const size_t nb = (size_t)n / 2;                // nodes of the second heap that have a child
     try {
-        dev.resize(4 * ((size_t)n + 1) + 1);
+        dev.resize(4 * ((size_t)n + 1) + 1 + 2 * (nb + 2));
         rt_photon_product_order(heap, n, src, pplane);
     } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
     memset(dev.data(), 0, sizeof(DevPhotonPos));
@@ -71,6 +72,19 @@ int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
             memcpy(pp[j].pos, p.position, 12); memcpy(pq[j].power, p.power, 12);
             pp[j].packed = ((uint32_t)pplane[(size_t)j] & 3u) | (reachable ? 0u : RT_PH_UNREACHABLE) | ((uint32_t)p.theta << 8) | ((uint32_t)p.phi << 16);
             pq[j].pad = (uint32_t)r;
+        }
+        // bounding boxes of the sub-heaps, bottom up: box[i] = photon i + box[2i] + box[2i+1]; corners as two 16-byte records
+        DevPhotonPos* bx = reinterpret_cast<DevPhotonPos*>(pq + (size_t)n + 1);
+        memset(bx, 0, 2 * (nb + 2) * sizeof(DevPhotonPos));
+        for (int64_t i = (int64_t)nb; i >= 1; --i) {
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) lo[a] = hi[a] = pp[i].pos[a];
+            for (int64_t c = 2 * i; c <= 2 * i + 1 && c <= n; ++c)
+                for (int a = 0; a < 3; ++a) {
+                    const float cl = c <= (int64_t)nb ? bx[2 * c].pos[a] : pp[c].pos[a], ch = c <= (int64_t)nb ? bx[2 * c + 1].pos[a] : pp[c].pos[a];
+                    lo[a] = std::min(lo[a], cl); hi[a] = std::max(hi[a], ch);
+                }
+            memcpy(bx[2 * i].pos, lo, 12); memcpy(bx[2 * i + 1].pos, hi, 12);
         }
     }
     hipError_t e = hipMalloc((void**)&m.d_photons, dev.size() * sizeof(DevPhotonPos));

@@ -86,7 +86,8 @@ struct DevPhotonPow { float power[3]; uint32_t pad; };     // pad: second heap o
 static_assert(sizeof(DevPhotonPos) == 16 && sizeof(DevPhotonPow) == 16, "photon records must be 16 bytes");
 // base pointer of the allocation: [n+1] DevPhotonPos, [n+1] DevPhotonPow in the REFERENCE's heap order, then the same
 // photons again in the order of rt_photon_product_order: [n+2] DevPhotonPos (one padding record: both children are
-// fetched together), [n+1] DevPhotonPow
+// fetched together), [n+1] DevPhotonPow, and [2 (n/2 + 2)] box corners: records 2i, 2i+1 = lo, hi of the bounding box of
+// the sub-heap of node i, for the n/2 nodes that have a child
 typedef DevPhotonPos DevPhoton;
 #define RT_PH_UNREACHABLE 4u      // second heap: the reference's LocatePhoton never reaches this photon (Q8)
 
@@ -226,8 +227,8 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
                                int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
                                float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st);
 hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, const float* d_pos3, const float* d_nrm3,
-                               int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, uint8_t* d_flagged,
-                               void* d_work, unsigned long long* d_stats, hipStream_t st);
+                               int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, int32_t* d_redo_list,
+                               unsigned* d_redo_count, void* d_work, unsigned long long* d_stats, hipStream_t st);
 size_t rtk_photon_irr_wave_workspace(int64_t q);
 size_t rtk_knn_fast_scratch_bytes(int64_t q);
 #define RT_KNN_FAST_KMAX 112
