@@ -242,10 +242,11 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
  *                  reference's order, irradiance summed in that order (bit-identical to the reference).
  *                  rt_photon_knn / rt_photon_knn_dev always run this one.
  *   RT_KNN_FAST    (default, k <= 112) the SET the reference finds, by other means.  Irradiance: 64 neighbouring
- *                  queries share one walk of the photon heap, each keeps the k smallest dist2 in registers
- *                  (DESIGN 4.3c); rt_photon_knn_set: 16 lanes per query with the reference's visits.
- *                  Queries whose set depends on the reference's heap history (exact ties), and waves whose walk
- *                  does not end within its budget, are redone strictly.  The irradiance adds the same photons in
+ *                  queries share one walk of a second, spatially ordered heap over the same photons, each keeps
+ *                  the k+1 smallest dist2 in registers; a short replay on the reference's heap tells which photon
+ *                  its list code evicts; rt_photon_knn_set: 16 lanes per query with the reference's
+ *                  visits.  Queries whose set depends on the reference's heap history (exact ties),
+ *                  and waves whose walk does not end within its budget, are redone strictly.  The irradiance adds the same photons in
  *                  another order: equal up to float association (<= 1e-5 relative in the tests).
  * RT_KNN=strict|fast sets the default of new scenes.                                                          */
 #define RT_OPT_KNN          2
