@@ -126,7 +126,7 @@ def cpu_baseline(sd, res):
                 rays=int(rays))
 
 
-def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, steps=3):
+def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, steps=3, with_cpu=True):
     """BASELINE configuration 4's shape: kNN radiance lookups/s on a synthetic photon map (positions on
     the walls of the Final scene's unit box; GPU emission is not built yet), queries on the floor/walls."""
     from raytracer_amd import abi
@@ -171,17 +171,21 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     scene_handle.knn_stats(True)
     run(); torch.cuda.synchronize()
     ks = scene_handle.knn_stats(False)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as ol
-    ns = min(2000, n_queries)
-    sel = np.linspace(0, n_queries - 1, ns).astype(np.int64)
-    qs = np.ascontiguousarray(q[sel])
-    idx = np.zeros((ns, k), np.int32); d2 = np.zeros((ns, k), np.float32); fnd = np.zeros(ns, np.int32); vis = C.c_int64(0)
-    t0 = time.perf_counter()
-    ol.oracle().orc_pmap_knn(a.ctypes.data, n_photons, qs.ctypes.data, ns, k, radius, idx.ctypes.data, d2.ctypes.data,
-                             fnd.ctypes.data, None, C.byref(vis))
-    cpu_s = time.perf_counter() - t0
-    ref_visits = vis.value / ns
+    ref_visits, found_mean, cpu = None, float(k), None
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        ns = min(2000, n_queries)
+        sel = np.linspace(0, n_queries - 1, ns).astype(np.int64)
+        qs = np.ascontiguousarray(q[sel])
+        idx = np.zeros((ns, k), np.int32); d2 = np.zeros((ns, k), np.float32); fnd = np.zeros(ns, np.int32); vis = C.c_int64(0)
+        t0 = time.perf_counter()
+        ol.oracle().orc_pmap_knn(a.ctypes.data, n_photons, qs.ctypes.data, ns, k, radius, idx.ctypes.data, d2.ctypes.data,
+                                 fnd.ctypes.data, None, C.byref(vis))
+        cpu_s = time.perf_counter() - t0
+        ref_visits = vis.value / ns
+        found_mean = float(fnd.mean())
+        cpu = dict(value=ns / cpu_s, unit="lookups/s", cores=1, kind="port", sample=f"{ns} of the same queries, oracle LocatePhoton")
     if ks[6] > 0:          # the wave-shared kernels ran
         visits = float(ks[0] + ks[12]) / n_queries
         detail = dict(kernel="k_irr_main", waves=int(ks[6]), phase1_fetches_per_lookup=float(ks[0]) / n_queries,
@@ -189,8 +193,8 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
                       strict_redo_queries=int(ks[5]), waves_gave_up=int(ks[11]), longest_wave_ms=float(int(ks[8]) >> 24) * 1e-5)
         tkey = "knn_10m.k_irr_main"
     else:
-        visits, detail, tkey = ref_visits, dict(kernel="k_photon_knn"), "knn_10m.k_photon_knn"
-    bytes_per = 24 + 16 * visits + 12 * float(fnd.mean()) + 12
+        visits, detail, tkey = (ref_visits or 0.0), dict(kernel="k_photon_knn"), "knn_10m.k_photon_knn"
+    bytes_per = 24 + 16 * visits + 12 * found_mean + 12
     gbs = bytes_per * n_queries / (ms * 1e-3) / 1e9
     return dict(metric="kNN radiance lookups/s", value=n_queries / (ms * 1e-3), unit="lookups/s",
                 config=dict(workload="synthetic photon map on the Final scene's box walls", photons=n_photons,
@@ -199,8 +203,7 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
                 roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
                               traffic=_traffic(tkey), visits_per_lookup=visits, bytes_per_lookup=bytes_per,
                               reference_visits_per_lookup=ref_visits, **detail),
-                cpu_baseline=dict(value=ns / cpu_s, unit="lookups/s", cores=1, kind="port",
-                                  sample=f"{ns} of the same queries, oracle LocatePhoton"))
+                cpu_baseline=cpu)
 
 
 def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500):
@@ -507,7 +510,7 @@ def main():
                            "any_hit_ms_per_step": tot["any_ms"] / args.steps,
                            "note": "scene (4 KB nodes + 100 KB leaf triangles) is cache resident: algorithmic bytes are served "
                                    "by the scalar cache / L2, not HBM; see DESIGN.md"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and n == 1:      # the CPU leg is timed at N = 1 only
             w, h = (int(x) for x in args.cpu_sample.split("x"))
             out["cpu_baseline"] = cpu_baseline(sd, (w, h))
         if not args.no_knn and n == 1:
@@ -523,6 +526,25 @@ def main():
                 except Exception as e:           # a secondary line must never take the headline down with it
                     sec[name] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
+    if n > 1 and not args.no_knn:
+        # the metric's second half at N GPUs: every rank answers its own share of the radiance lookups (the queries
+        # follow their pixels, the photon map is replicated, no exchange: SURVEY 8e), weak scaling like the frame
+        try:
+            r = knn_secondary(gs, torch, args.knn_photons, args.knn_queries, steps=3, with_cpu=False)
+            ms = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
+        except Exception as e:
+            log(f"rank {rank}: kNN line failed: {type(e).__name__}: {e}")
+            r, ms = None, torch.tensor([float("inf")], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            if r is not None and ms.item() != float("inf"):
+                r["value"] = n * args.knn_queries / (ms.item() * 1e-3)
+                r["ms_per_step"] = ms.item(); r["n_gpus"] = n
+                r["config"]["queries"] = n * args.knn_queries
+                r["note"] = "aggregate over the ranks: each answers its own queries on its replica of the map; time = slowest rank"
+                out["secondary"] = {"knn": r}
+            else:
+                out["secondary"] = {"knn": {"error": "a rank failed"}}
     if n > 1:
         dist.barrier()
         dist.destroy_process_group()
