@@ -408,7 +408,7 @@ def main():
     final = torch.zeros((npix, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
     all_pix = [torch.from_numpy(rank_pixel_index(resx, resy, r, n)).to(dev) for r in range(n)] if (n > 1 and rank == 0) else None
     st = abi.rt_stats()
-    tot = dict(rays=0, closest_ms=0.0, any_ms=0.0, closest_launches=0, closest_rays=0)
+    tot = dict(rays=0, closest_ms=0.0, any_ms=0.0, closest_launches=0, closest_rays=0, any_launches=0, shadow_rays=0)
     pending = [None, None]
 
     def step(i, timed):
@@ -422,6 +422,7 @@ def main():
                 tot["rays"] += st.rays_primary + st.rays_shadow
                 tot["closest_ms"] += st.trace_closest_ms; tot["any_ms"] += st.trace_any_ms
                 tot["closest_launches"] += st.trace_closest_launches; tot["closest_rays"] += st.rays_primary
+                tot["any_launches"] += st.trace_any_launches; tot["shadow_rays"] += st.rays_shadow
         if n > 1:
             if pending[b] is not None:                # the buffer pair of two steps ago must have left
                 pending[b].wait()
@@ -499,17 +500,25 @@ def main():
         launches = max(1, tot["closest_launches"])
         rays_per_launch = tot["closest_rays"] / launches
         avg_ms = tot["closest_ms"] / launches
-        gbs = alg["bytes_per_ray"] * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = _traffic("monkey_4k.k_trace_closest")
+        fused = tot["any_launches"] == 0 and tot["shadow_rays"] > 0       # the whole frame is ONE kernel (k_primary_only)
+        shadow_per_launch = tot["shadow_rays"] / launches
+        bytes_per_launch = alg["bytes_per_ray"] * rays_per_launch + (alg["any_bytes_per_ray"] * shadow_per_launch if fused else 0.0)
+        gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kernel = "k_primary_only" if fused else "k_trace_closest"
+        traffic = _traffic("monkey_4k." + kernel)
         out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": "k_trace_closest", "avg_launch_ms": avg_ms,
-                           "rays_per_launch": rays_per_launch, "bytes_per_ray": alg["bytes_per_ray"],
+                           "traffic": traffic, "kernel": kernel, "avg_launch_ms": avg_ms,
+                           "rays_per_launch": rays_per_launch + (shadow_per_launch if fused else 0.0),
+                           "bytes_per_ray": alg["bytes_per_ray"],
                            "box_tests_per_ray": alg["box_tests_per_ray"], "tri_tests_per_ray": alg["tri_tests_per_ray"],
                            "exact_tri_tests_per_ray": alg["exact_tri_tests_per_ray"],
                            "any_hit_bytes_per_ray": alg["any_bytes_per_ray"],
                            "any_hit_ms_per_step": tot["any_ms"] / args.steps,
-                           "note": "scene (4 KB nodes + 100 KB leaf triangles) is cache resident: algorithmic bytes are served "
-                                   "by the scalar cache / L2, not HBM; see DESIGN.md"}
+                           "note": ("one fused kernel traces the primary AND the shadow rays (generate, closest hit, any hit, shade, "
+                                    "pixel): algorithmic bytes of both. " if fused else "") +
+                                   "The scene (4 KB nodes + 100 KB leaf triangles) is cache resident: the algorithmic bytes are "
+                                   "served by the scalar cache / L2, not HBM, and the kernel is bound by vector-instruction issue "
+                                   "(SQ counters: 93 % of the issue slots, profiles/r01_sq_monkey_4k.json); see DESIGN.md"}
         if not args.no_cpu_baseline and n == 1:      # the CPU leg is timed at N = 1 only
             w, h = (int(x) for x in args.cpu_sample.split("x"))
             out["cpu_baseline"] = cpu_baseline(sd, (w, h))

@@ -237,6 +237,10 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
 #define RT_TRAVERSAL_FAST   1
 #define RT_TRAVERSAL_LANE   2
 #define RT_OPT_LANE_DEPTH   3
+/* RT_OPT_FUSED_PRIMARY (default 1): with rt_params.primary_only, RT_TRAVERSAL_FAST, one sample per pixel and <= 32
+ * lights, rt_render runs the whole frame (camera ray, closest hit, shadow rays, shading, pixel) as one kernel instead
+ * of the wavefront passes: same bytes, no intermediate arrays.  0 = always the passes.  RT_FUSED_PRIMARY=0|1.       */
+#define RT_OPT_FUSED_PRIMARY 5
 /* Algorithm of the radiance estimate (rt_photon_irradiance*, the photon renderer) and of rt_photon_knn_set:
  *   RT_KNN_STRICT  LocatePhoton's array / heap code statement by statement, one query per lane: np.index in the
  *                  reference's order, irradiance summed in that order (bit-identical to the reference).

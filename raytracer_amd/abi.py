@@ -20,6 +20,7 @@ RT_OPT_TRAVERSAL, RT_TRAVERSAL_STRICT, RT_TRAVERSAL_FAST, RT_TRAVERSAL_LANE = 1,
 RT_OPT_KNN, RT_KNN_STRICT, RT_KNN_FAST = 2, 0, 1
 RT_OPT_LANE_DEPTH = 3
 RT_OPT_KNN_STATS = 4
+RT_OPT_FUSED_PRIMARY = 5
 
 _f, _i32, _i64, _u8 = C.c_float, C.c_int32, C.c_int64, C.c_uint8
 

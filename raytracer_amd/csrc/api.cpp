@@ -222,6 +222,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->eps_f = rt_float_above(0.000001);          // `epsilon`, hw4.cpp:18
     s->nprim = d->nprim;
     if (const char* e = getenv("RT_TRAVERSAL")) s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "lane") == 0) ? 2 : 1;
+    if (const char* e = getenv("RT_FUSED_PRIMARY")) s->fused_primary = atoi(e) != 0;
     if (const char* e = getenv("RT_LANE_DEPTH")) s->lane_depth = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("RT_KNN")) s->knn_fast = (strcmp(e, "strict") == 0) ? 0 : 1;
 
@@ -260,6 +261,7 @@ int rt_scene_set_option(rt_scene* s, int option, int value) {
     if (!s) return rt_fail(RT_E_INVALID, "rt_scene_set_option: NULL scene");
     if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST || value == RT_TRAVERSAL_LANE)) { s->fast = value; return RT_OK; }
     if (option == RT_OPT_LANE_DEPTH && value >= 0) { s->lane_depth = value; return RT_OK; }
+    if (option == RT_OPT_FUSED_PRIMARY && (value == 0 || value == 1)) { s->fused_primary = value; return RT_OK; }
     if (option == RT_OPT_KNN_STATS && (value == 0 || value == 1)) {
         DeviceGuard g(s->device);
         if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");

@@ -17,47 +17,9 @@
 // depend on how the frame is tiled over GPUs.
 #include <hip/hip_runtime.h>
 #include "rt_internal.h"
+#include "shade_device.h"
 #include "rng_device.h"
 
-namespace {
-
-__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
-__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {     // algebra3.cpp:280-282,301
-    const float len = sqrt_rn(x * x + y * y + z * z);
-    const float di = (float)(1.0 / (double)len);
-    x *= di; y *= di; z *= di;
-}
-__device__ __forceinline__ float max_std(float a, float b) { return (a < b) ? b : a; }   // std::max
-
-struct HitCtx {
-    float ox, oy, oz, dx, dy, dz;      // the ray
-    float hx, hy, hz;                  // hitPoint
-    float nx, ny, nz;                  // normal, flipped against the ray (hw4.cpp:888-891)
-    int prim, mat;
-};
-
-__device__ __forceinline__ bool load_hit(const DevSceneView& sc, const rt_ray* __restrict__ rays,
-                                         const rt_hit* __restrict__ hits, int64_t i, HitCtx& c) {
-    const float* h = reinterpret_cast<const float*>(hits + i);
-    c.prim = reinterpret_cast<const int32_t*>(h)[0];
-    if (c.prim < 0) return false;
-    c.hx = h[2]; c.hy = h[3]; c.hz = h[4];
-    const float* r = reinterpret_cast<const float*>(rays + i);
-    c.ox = r[0]; c.oy = r[1]; c.oz = r[2]; c.dx = r[3]; c.dy = r[4]; c.dz = r[5];
-    c.mat = sc.prim_material[c.prim];
-    if (sc.prim_type[c.prim] == RT_PRIM_SPHERE) {                 // Sphere::GetNormal, hw4.cpp:118-120
-        const float* g = sc.prim_geom + 4 * (size_t)c.prim;
-        c.nx = c.hx - g[0]; c.ny = c.hy - g[1]; c.nz = c.hz - g[2];
-        normalize3(c.nx, c.ny, c.nz);
-    } else {                                                      // Triangle::GetNormal, hw4.cpp:122-137
-        const float* n = sc.prim_normal + 3 * (size_t)c.prim;
-        c.nx = n[0]; c.ny = n[1]; c.nz = n[2];
-    }
-    if (c.nx * c.dx + c.ny * c.dy + c.nz * c.dz > 0) { c.nx = -1.0f * c.nx; c.ny = -1.0f * c.ny; c.nz = -1.0f * c.nz; }
-    return true;
-}
-
-}  // namespace
 
 // counters[0]=valid rays in, [1]=hits, [3]=reflect children, [4]=refract children.
 // No global atomics: all waves of a frame adding to one address serialise (2 atomics per wave
@@ -120,8 +82,6 @@ k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __
             f0 = m.reflect > 0.0001f;                         // hw4.cpp:897
             f1 = (double)m.refract > 0.0001;                  // hw4.cpp:907 (double literal)
         }
-        // IsInShadow's ray, hw4.cpp:961-963
-        const float bx = c.hx + sc.shadow_bias * c.nx, by = c.hy + sc.shadow_bias * c.ny, bz = c.hz + sc.shadow_bias * c.nz;
         for (int l = 0; l < L; ++l) {
             const DevLight lt = sc.lights[l];
             float lx = lt.pos[0], ly = lt.pos[1], lz = lt.pos[2];
@@ -130,10 +90,7 @@ k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __
                 rt_ball(seed, ((uint64_t)px << 16) | (code[i] >> 16), code[i] & 0xffffu, 16 + 8 * l, b3);
                 lx = lx + light_radius * b3[0]; ly = ly + light_radius * b3[1]; lz = lz + light_radius * b3[2];
             }
-            float dx = lx - bx, dy = ly - by, dz = lz - bz;
-            normalize3(dx, dy, dz);
-            float* o = reinterpret_cast<float*>(srays + (i * L + l));
-            o[0] = bx; o[1] = by; o[2] = bz; o[3] = dx; o[4] = dy; o[5] = dz;
+            shadow_ray(sc, c, lx, ly, lz, reinterpret_cast<float*>(srays + (i * L + l)));
             sactive[i * L + l] = 0;
         }
     } else {
@@ -156,30 +113,8 @@ k_shade_lights(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* _
     const bool hit = inb && pix[i] >= 0 && load_hit(sc, rays, hits, i, c);
     if (!inb) return;
     if (hit) {
-        const DevMaterial m = sc.materials[c.mat];
-        // ambient = (surfColor * ambientIntensity) * Ka
-        cr = (ambient_intensity * m.surf[0]) * m.Ka; cg = (ambient_intensity * m.surf[1]) * m.Ka; cb = (ambient_intensity * m.surf[2]) * m.Ka;
-        float dr = 0, dg = 0, db = 0, sr = 0, sg = 0, sb = 0;
         const int L = sc.nlights;
-        for (int l = 0; l < L; ++l) {
-            if (!occluded[i * L + l]) {
-                const DevLight lt = sc.lights[l];
-                float tx = lt.pos[0] - c.hx, ty = lt.pos[1] - c.hy, tz = lt.pos[2] - c.hz;
-                normalize3(tx, ty, tz);
-                float dot = max_std(tx * c.nx + ty * c.ny + tz * c.nz, 0.0f);
-                const float ir = lt.intensity * m.surf[0], ig = lt.intensity * m.surf[1], ib = lt.intensity * m.surf[2];
-                const float kd = m.Kd * dot;
-                dr = kd * ir; dg = kd * ig; db = kd * ib;
-                float ex = eyex - c.hx, ey = eyey - c.hy, ez = eyez - c.hz;
-                normalize3(ex, ey, ez);
-                float hx = ex + tx, hy = ey + ty, hz = ez + tz;
-                normalize3(hx, hy, hz);
-                dot = max_std(hx * c.nx + hy * c.ny + hz * c.nz, 0.0f);
-                const float pw = powf(dot, m.specularity);
-                sr = pw * (m.Ks * ir); sg = pw * (m.Ks * ig); sb = pw * (m.Ks * ib);
-            }
-            cr = (cr + dr) + sr; cg = (cg + dg) + sg; cb = (cb + db) + sb;
-        }
+        shade_local(sc, c, ambient_intensity, eyex, eyey, eyez, [&](int l) { return occluded[i * L + l] != 0; }, cr, cg, cb);
         const float w = weight ? weight[i] : 1.0f;
         cr *= w; cg *= w; cb *= w;
     }
@@ -316,13 +251,6 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
 }
 
 // GenerateColorImage's pixel write, hw4.cpp:1108-1122.  One thread per primary ray of this rank.
-__device__ __forceinline__ uint8_t quantize(float c) {
-    if (c > 1.0f) return 255;
-    const float v = c * 255.0f;
-    if (!(v > -2147483648.0f && v < 2147483648.0f)) return 0;     // cvttss2si's 0x80000000 -> low byte 0
-    return (uint8_t)(int32_t)v;
-}
-
 extern "C" __global__ void __launch_bounds__(256)
 k_finalize(const int32_t* __restrict__ pix0, int64_t n, const float* __restrict__ accum,
            const uint8_t* __restrict__ hit_any, float bgr, float bgg, float bgb, uint8_t* __restrict__ rgb8) {
@@ -370,6 +298,12 @@ hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_
                        primary_pass, child_flags, srays, sactive, hit_ids, hit_any,
                        reinterpret_cast<unsigned long long*>(block_pairs), code, seed, light_radius);
     hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, block_pairs, (int64_t)nb, counters);
+    return hipGetLastError();
+}
+
+hipError_t rtk_reduce_pairs(const unsigned int* block_pairs, int64_t nblocks, unsigned long long* counters, hipStream_t st) {
+    if (nblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, block_pairs, nblocks, counters);
     return hipGetLastError();
 }
 

@@ -100,6 +100,9 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     };
     if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
 
+    // BASELINE configuration 2 (primary + shadow rays, one centre sample) has a kernel of its own
+    const bool fused = s->fused_primary && p->primary_only && !drt && s->fast == 1 && !(stats && p->count_work) &&
+                       L <= rtk_primary_only_max_lights();
     int64_t passes = 0;
     std::vector<int64_t> pass_n;      // rays of every pass (RT_TRACE_PASSES=1 prints them with the kernel times)
     for (int64_t tile0 = 0; tile0 < ntiles; tile0 += chunk_tiles) {
@@ -110,6 +113,19 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const int32_t* pixlist = (const int32_t*)pix0;      // one entry per pixel slot of this chunk (zero / finalize)
     const float* q_w = nullptr;          // NULL = weight 1
     const uint32_t* q_code = nullptr;    // NULL = no sample bookkeeping (the reference's single centre sample)
+    if (fused) {
+        // primary + shadow rays only: the chunk's whole frame in one kernel (kernels_primary.hip); nothing goes through HBM
+        // but the pixels.  Timed as the "closest" kernel; there is no separate any-hit launch.
+        const int64_t nblocks = ctiles;                       // one pair of counts per wave
+        void* pairs; RTCHK(s->scratch(S_PAIRS, (size_t)nblocks * 8 + 16, &pairs));
+        ++passes; pass_n.push_back(n0);
+        RTCHK(mark());
+        HIPCHK(rtk_primary_only(s->view, *cam, c_tiles, ctiles, s->eps_f, p->ambient_intensity, p->background, d_rgb8, d_hit_ids,
+                                s->d_radiance_out, (unsigned int*)pairs, st), "k_primary_only");
+        RTCHK(mark()); RTCHK(mark()); RTCHK(mark());
+        HIPCHK(rtk_reduce_pairs((const unsigned int*)pairs, nblocks, d_ctr, st), "k_reduce_pairs");
+        continue;
+    }
     if (drt) {
         void *w0, *code0, *pl;
         RTCHK(s->scratch(S_W0, (size_t)n0 * 4, &w0));
@@ -214,7 +230,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             HIPCHK(hipEventElapsedTime(&a, kev[i], kev[i + 1]), "event time");
             HIPCHK(hipEventElapsedTime(&b, kev[i + 2], kev[i + 3]), "event time");
             stats->trace_closest_ms += a; stats->trace_any_ms += b;
-            stats->trace_closest_launches += 1; stats->trace_any_launches += (L > 0) ? 1 : 0;
+            stats->trace_closest_launches += 1; stats->trace_any_launches += (L > 0 && !fused) ? 1 : 0;
             if (getenv("RT_TRACE_PASSES"))
                 fprintf(stderr, "pass %zu: %lld rays, closest %.3f ms, any %.3f ms\n", i / 4, (long long)pass_n[i / 4], a, b);
         }

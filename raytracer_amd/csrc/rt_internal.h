@@ -170,6 +170,12 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
                                 float* onr, unsigned long long* counters, const uint32_t* code, uint32_t* ocode,
                                 uint64_t seed, float glossy, hipStream_t st);
+hipError_t rtk_reduce_pairs(const unsigned int* block_pairs, int64_t nblocks, unsigned long long* counters, hipStream_t st);
+// kernels_primary.hip: the primary + shadow frame in one kernel (rt_params.primary_only, fast traversal, <= 32 lights)
+int rtk_primary_only_max_lights();
+hipError_t rtk_primary_only(const DevSceneView& sc, const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float eps_f,
+                            float ambient, const float bg[3], uint8_t* d_rgb8, int32_t* d_hit_ids, float* d_radiance,
+                            unsigned int* d_block_pairs, hipStream_t st);
 hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
                         uint8_t* rgb8, hipStream_t st);
 hipError_t rtk_copy_radiance(const int32_t* pix0, int64_t n, const float* accum, float* out, hipStream_t st);

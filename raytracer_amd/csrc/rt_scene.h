@@ -26,6 +26,7 @@ struct rt_scene {
     unsigned long long* d_knn_stats = nullptr;   // 16 work counters of the wave-shared kNN kernels, NULL = not counting (RT_OPT_KNN_STATS)
     unsigned long long* d_knn_stats_buf = nullptr;
     int knn_fast = 1;                 // radiance estimate: 1 = wave-shared kernel (default), 0 = strict list replay
+    int fused_primary = 1;            // rt_render with primary_only: one kernel for the whole frame (RT_OPT_FUSED_PRIMARY)
     int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
     int fast = 1;                     // traversal: 1 = ordered + culled, 2 = the same per lane, 0 = strict reference order
     rt_scene_info info;

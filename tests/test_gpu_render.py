@@ -208,3 +208,42 @@ def test_chunked_frame_equals_unchunked(monkey_sd, monkeypatch):
     assert st2.rays_reflect == st.rays_reflect and st2.rays_shadow == st.rays_shadow
     assert np.array_equal(parts, whole) and np.array_equal(ids, ids2)
     g.close()
+
+
+def test_fused_primary_frame_equals_the_wavefront_passes(monkey_sd):
+    """rt_params.primary_only (BASELINE configuration 2) runs as ONE kernel (kernels_primary.hip) unless
+    RT_OPT_FUSED_PRIMARY is 0: pixels, hit ids, radiance and ray counts must be those of the wavefront passes, for the
+    whole frame, an odd resolution and a sharded frame; a scene with spheres and several lights too."""
+    g = host.Scene(monkey_sd)
+    for res in ((3840, 2160), (257, 131)):
+        cam = host.camera_for(monkey_sd, res)
+        outs = []
+        for fused in (1, 0):
+            abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_FUSED_PRIMARY, fused))
+            rgb, ids, st = g.render(cam, host.default_params("hw4", primary_only=1), want_ids=True)
+            rad, _ = g.render_radiance(cam, host.default_params("hw4", primary_only=1))
+            outs.append((rgb, ids, rad, (st.rays_primary, st.rays_shadow, st.rays_reflect, st.passes), st.trace_any_launches))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert outs[0][2].tobytes() == outs[1][2].tobytes() and outs[0][3] == outs[1][3]
+        assert outs[0][4] == 0 and outs[1][4] == 1                   # the fused frame has no separate any-hit launch
+    abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_FUSED_PRIMARY, 1))
+    res = (640, 360)
+    cam = host.camera_for(monkey_sd, res)
+    whole, _, _ = g.render(cam, host.default_params("hw4", primary_only=1))
+    acc = np.zeros(res[0] * res[1] * 3, np.uint8)
+    for r in range(3):
+        p = host.default_params("hw4", primary_only=1, tile_size=64, tile_rank=r, tile_nranks=3)
+        abi.check(g.L.rt_render(g.h, C.byref(cam), C.byref(p), acc.ctypes.data, None, None))
+    assert np.array_equal(acc.reshape(res[1], res[0], 3), whole)
+    g.close()
+    sd = scene.parse_scene_text("""E 0 0 -3 V 0 0 1 F 50 R 64 64
+        ML 2 3 -2 1 1 1 0.8  ML -3 1 -1 1 0.5 0.5 0.6  L 0 5 0
+        M 0.8 0.2 0.2 0.1 0.6 0.5 20 0 0 1  S 0 0 1 0.8  S 0.9 0.5 0.2 0.3
+        M 0.2 0.8 0.3 0.2 0.7 0.2 8 0 0 1  T -3 -1 -1  3 -1 -1  0 -1 4  0 1 0  O""")
+    g = host.Scene(sd)
+    cam = host.camera_for(sd, (200, 120))
+    a, ia, _ = g.render(cam, host.default_params("hw4", primary_only=1), want_ids=True)
+    abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_FUSED_PRIMARY, 0))
+    b, ib, _ = g.render(cam, host.default_params("hw4", primary_only=1), want_ids=True)
+    assert np.array_equal(a, b) and np.array_equal(ia, ib) and (ia >= 0).any() and (a != a[0, 0]).any()
+    g.close()
