@@ -43,7 +43,7 @@ static_assert(sizeof(DevLeafTri) == 48, "DevLeafTri must be 48 bytes");
 // Inside a leaf the records are sorted along a Morton curve and cut into groups of <= RT_GROUP consecutive
 // records; a group carries the bounding box of its triangles.  The fast traversal skips a group whose (inflated)
 // box a ray misses or that lies beyond its best hit -- a culling layer under the reference's tree.
-#define RT_GROUP 8
+#define RT_GROUP 6
 struct DevLeafGroup {       // 64 B
     float lo[3]; float hi[3];
     float gm;               // max |edge1|*|edge2| over the group's triangles
