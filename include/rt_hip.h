@@ -236,6 +236,7 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
 #define RT_TRAVERSAL_STRICT 0
 #define RT_TRAVERSAL_FAST   1
 #define RT_TRAVERSAL_LANE   2
+#define RT_TRAVERSAL_BVH    3
 #define RT_OPT_LANE_DEPTH   3
 /* RT_OPT_FUSED_PRIMARY (default 1): with rt_params.primary_only, RT_TRAVERSAL_FAST, one sample per pixel and <= 32
  * lights, rt_render runs the whole frame (camera ray, closest hit, shadow rays, shading, pixel) as one kernel instead

@@ -16,7 +16,7 @@ RT_LIGHT_POINT, RT_LIGHT_RECT = 0, 1
 RT_SCENE_CULLING, RT_SCENE_KD_REFERENCE = 1, 2
 RT_RENDER_WHITTED, RT_RENDER_PHOTON = 0, 1
 RT_PMAP_GLOBAL, RT_PMAP_CAUSTIC = 0, 1
-RT_OPT_TRAVERSAL, RT_TRAVERSAL_STRICT, RT_TRAVERSAL_FAST, RT_TRAVERSAL_LANE = 1, 0, 1, 2
+RT_OPT_TRAVERSAL, RT_TRAVERSAL_STRICT, RT_TRAVERSAL_FAST, RT_TRAVERSAL_LANE, RT_TRAVERSAL_BVH = 1, 0, 1, 2, 3
 RT_OPT_KNN, RT_KNN_STRICT, RT_KNN_FAST = 2, 0, 1
 RT_OPT_LANE_DEPTH = 3
 RT_OPT_KNN_STATS = 4

@@ -151,6 +151,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     int rc;
     try {
         rc = rt_build_flat_scene(d, &flat, &err);
+        if (!rc) rc = rt_build_bvh(d, &flat, &err);
     } catch (const std::bad_alloc&) {
         return rt_fail(RT_E_NOMEM, "host allocation failed while building the KD-trees");
     }
@@ -201,6 +202,13 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!rc) rc = upload(s, flat.leaf_tris, &v.leaf_tris);
     if (!rc) rc = upload(s, flat.leaf_groups, &v.leaf_groups);
     if (!rc) rc = upload(s, flat.loose, &v.loose);
+    for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.bvh_nodes[o], &v.bvh_oct[o]);
+    v.nbvh = (int32_t)flat.bvh_nodes[0].size();
+    if (!rc) rc = upload(s, flat.bvh_tris, &v.bvh_tris);
+    if (!rc) rc = upload(s, flat.bvh_tri_ref, &v.bvh_tri_ref);
+    if (!rc) rc = upload(s, flat.bvh_ref_leaf, &v.bvh_ref_leaf);
+    if (!rc) rc = upload(s, flat.ref_parent, &v.ref_parent);
+    if (!rc) rc = upload(s, flat.ref_chain_box, &v.ref_chain_box);
     if (!rc) rc = upload(s, flat.prim_normal, &v.prim_normal);
     if (!rc) rc = upload(s, flat.prim_geom, &v.prim_geom);
     if (!rc) rc = upload(s, pmat, &v.prim_material);
@@ -221,7 +229,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.shadow_bias = d->shadow_bias; v.refract_bias = d->refract_bias;
     s->eps_f = rt_float_above(0.000001);          // `epsilon`, hw4.cpp:18
     s->nprim = d->nprim;
-    if (const char* e = getenv("RT_TRAVERSAL")) s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "lane") == 0) ? 2 : 1;
+    if (const char* e = getenv("RT_TRAVERSAL")) s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "lane") == 0) ? 2 : (strcmp(e, "bvh") == 0) ? 3 : 1;
     if (const char* e = getenv("RT_FUSED_PRIMARY")) s->fused_primary = atoi(e) != 0;
     if (const char* e = getenv("RT_LANE_DEPTH")) s->lane_depth = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("RT_KNN")) s->knn_fast = (strcmp(e, "strict") == 0) ? 0 : 1;
@@ -259,7 +267,7 @@ int rt_scene_knn_stats(rt_scene* s, int64_t out16[16]) {
 
 int rt_scene_set_option(rt_scene* s, int option, int value) {
     if (!s) return rt_fail(RT_E_INVALID, "rt_scene_set_option: NULL scene");
-    if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST || value == RT_TRAVERSAL_LANE)) { s->fast = value; return RT_OK; }
+    if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST || value == RT_TRAVERSAL_LANE || value == RT_TRAVERSAL_BVH)) { s->fast = value; return RT_OK; }
     if (option == RT_OPT_LANE_DEPTH && value >= 0) { s->lane_depth = value; return RT_OK; }
     if (option == RT_OPT_FUSED_PRIMARY && (value == 0 || value == 1)) { s->fused_primary = value; return RT_OK; }
     if (option == RT_OPT_KNN_STATS && (value == 0 || value == 1)) {

@@ -1,0 +1,251 @@
+// bvh_build.cpp -- host side of the build's OWN hierarchy over a scene's tree triangles.
+//
+// The reference's KD-tree (scene_build.cpp) decides WHICH triangles a ray may hit: only those in a leaf whose chain of
+// boxes the ray passes (KDNode::HitTest, hw4.cpp:281-328).  It is a poor index, though (monkey: leaves of ~30
+// overlapping triangles, every triangle in 2.2 leaves, 42 box + 66 triangle tests per primary ray).  This file builds
+// a second index over the same triangles -- a binary BVH, median splits of the centroids, <= RT_GROUP triangles per
+// leaf, every triangle once -- that the fast traversal walks instead; a hit found through it counts only if the
+// reference could have found it, which the device checks per accepted hit against the reference's own boxes
+// (trace_device.h: reachable_rank).  What is kept per triangle for that check: the reference leaves that hold it, in
+// the reference's visit order.
+#include "rt_internal.h"
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+namespace {
+
+struct BNode {
+    int64_t a = 0, b = 0;               // range of `idx`
+    int axis = 0;
+    std::unique_ptr<BNode> l, r;
+    float lo[3], hi[3];
+    float gm = 0.f, amin = 0.f;
+    float cone[3] = {0, 0, 1}, cos_t = 0.f, sin_t = 1.f;
+    bool use_cone = false;
+};
+
+constexpr int64_t CONE_MAX = 256;      // subtrees up to this many triangles get a normal cone of their own
+
+struct BvhBuilder {
+    const rt_scene_desc* d;
+    std::vector<int32_t> idx;           // triangle (scene prim) ids, partitioned in place
+    std::vector<float> gm_of;           // per scene prim: |e1| |e2|
+    size_t par_min;
+
+    float centroid(int32_t p, int ax) const { const float* f = d->prims[p].f; return (f[ax] + f[3 + ax] + f[6 + ax]) * (1.0f / 3.0f); }
+
+    void leaf_stats(BNode& n) const {
+        float gm = 0.f; double amin = 1e300, ax[3] = {0, 0, 0};
+        std::vector<std::array<double, 3>> nrm;
+        const bool want_cone = n.b - n.a <= CONE_MAX;
+        for (int k = 0; k < 3; ++k) { n.lo[k] = 1e30f; n.hi[k] = -1e30f; }
+        for (int64_t j = n.a; j < n.b; ++j) {
+            const float* f = d->prims[idx[(size_t)j]].f;
+            float e1[3], e2[3];
+            for (int k = 0; k < 3; ++k) {
+                e1[k] = f[3 + k] - f[k]; e2[k] = f[6 + k] - f[k];
+                for (int v = 0; v < 3; ++v) { n.lo[k] = std::min(n.lo[k], f[3 * v + k]); n.hi[k] = std::max(n.hi[k], f[3 * v + k]); }
+            }
+            const float l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+            gm = std::max(gm, l1 * l2);
+            const double cx = (double)e1[1] * e2[2] - (double)e1[2] * e2[1], cy = (double)e1[2] * e2[0] - (double)e1[0] * e2[2],
+                         cz = (double)e1[0] * e2[1] - (double)e1[1] * e2[0];
+            const double ar = std::sqrt(cx * cx + cy * cy + cz * cz);
+            if (ar > 0) {
+                amin = std::min(amin, ar);
+                if (want_cone) {
+                    std::array<double, 3> u = {cx / ar, cy / ar, cz / ar};
+                    if (!nrm.empty() && u[0] * nrm[0][0] + u[1] * nrm[0][1] + u[2] * nrm[0][2] < 0) { u[0] = -u[0]; u[1] = -u[1]; u[2] = -u[2]; }
+                    nrm.push_back(u); ax[0] += u[0]; ax[1] += u[1]; ax[2] += u[2];
+                }
+            } else amin = 0.0;
+        }
+        n.gm = gm;
+        n.amin = amin >= 1e299 ? 0.f : (float)(amin * (1.0 - 1e-5));
+        n.use_cone = false;
+        if (want_cone && !nrm.empty() && amin > 0) {
+            const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            if (al > 1e-12) {
+                double cmin = 1.0;
+                for (const auto& u : nrm) cmin = std::min(cmin, (u[0] * ax[0] + u[1] * ax[1] + u[2] * ax[2]) / al);
+                cmin = std::max(-1.0, cmin - 1e-4);                  // round the cone outwards
+                if (cmin > 0.2) {                                     // wider cones bound nothing useful
+                    for (int k = 0; k < 3; ++k) n.cone[k] = (float)(ax[k] / al);
+                    n.cos_t = (float)cmin; n.sin_t = (float)std::min(1.0, std::sqrt(std::max(0.0, 1.0 - cmin * cmin)) + 1e-4);
+                    n.use_cone = true;
+                }
+            }
+        }
+    }
+
+    void build(BNode& n) {
+        const int64_t cnt = n.b - n.a;
+        if (cnt <= RT_GROUP) { leaf_stats(n); return; }
+        // A node's box is inflated in proportion to the LARGEST |e1| |e2| below it (trace_device.h: lateral_slack): a
+        // few big triangles among small ones (a floor under a mesh) would loosen every box above them.  They are
+        // split off by size first: triangles above 8 x the median product go to a child of their own.
+        int64_t mid = -1;
+        {
+            std::vector<float> g((size_t)cnt);
+            for (int64_t j = 0; j < cnt; ++j) g[(size_t)j] = gm_of[(size_t)idx[(size_t)(n.a + j)]];
+            std::nth_element(g.begin(), g.begin() + cnt / 2, g.end());
+            const float thr = 8.0f * g[(size_t)(cnt / 2)];
+            auto small_first = [this, thr](int32_t p) { return !(gm_of[(size_t)p] > thr); };
+            const int64_t nsmall = std::count_if(idx.begin() + n.a, idx.begin() + n.b, small_first);
+            if (nsmall < cnt && cnt - nsmall <= cnt / 4) {
+                std::stable_partition(idx.begin() + n.a, idx.begin() + n.b, small_first);
+                mid = n.a + nsmall;
+                n.axis = 0;
+            }
+        }
+        if (mid < 0) {
+            float clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
+            for (int64_t j = n.a; j < n.b; ++j)
+                for (int k = 0; k < 3; ++k) { const float c = centroid(idx[(size_t)j], k); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
+            int ax = 0;
+            if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+            if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+            n.axis = ax;
+            mid = n.a + cnt / 2;
+            std::nth_element(idx.begin() + n.a, idx.begin() + mid, idx.begin() + n.b, [this, ax](int32_t p, int32_t q) {
+                const float cp = centroid(p, ax), cq = centroid(q, ax);
+                return cp < cq || (cp == cq && p < q);
+            });
+        }
+        n.l.reset(new BNode()); n.r.reset(new BNode());
+        n.l->a = n.a; n.l->b = mid; n.r->a = mid; n.r->b = n.b;
+        if ((size_t)cnt >= par_min) {
+            std::thread other([this, &n] { build(*n.l); });
+            build(*n.r);
+            other.join();
+        } else { build(*n.l); build(*n.r); }
+        for (int k = 0; k < 3; ++k) { n.lo[k] = std::min(n.l->lo[k], n.r->lo[k]); n.hi[k] = std::max(n.l->hi[k], n.r->hi[k]); }
+        n.gm = std::max(n.l->gm, n.r->gm);
+        n.amin = std::min(n.l->amin, n.r->amin);
+        if (cnt <= CONE_MAX) {                                        // a cone of its own where it can be narrow
+            BNode tmp; tmp.a = n.a; tmp.b = n.b;
+            leaf_stats(tmp);
+            n.use_cone = tmp.use_cone; memcpy(n.cone, tmp.cone, sizeof n.cone); n.cos_t = tmp.cos_t; n.sin_t = tmp.sin_t;
+        }
+    }
+
+    void emit(const BNode& n, int depth, int o, std::vector<DevBvhNode>& out) const {
+        const size_t me = out.size();
+        out.emplace_back();
+        const bool leaf = !n.l;
+        if (!leaf) {
+            const bool right_first = (o >> n.axis) & 1;
+            emit(right_first ? *n.r : *n.l, depth + 1, o, out);
+            emit(right_first ? *n.l : *n.r, depth + 1, o, out);
+        }
+        DevBvhNode& r = out[me];
+        memcpy(r.lo, n.lo, 12); memcpy(r.hi, n.hi, 12);
+        {   // lateral_slack (trace_device.h) for |dir| in [0.999, 1.001], the rays traverse_bvh takes
+            const double g = 1.001 * (double)n.gm, d0 = 1e-6 - 4.0e-7 * g;
+            r.slack = d0 > 1e-12 ? (float)std::min(1e30, (1.2e-6 * g / d0) * (1.0 + 1e-6) + 2e-5) : 1e30f;
+            r.cone_k = n.amin > 0.f ? (float)std::min(1e30, (1.2e-6 * g / (0.999 * (double)n.amin)) * (1.0 + 1e-6)) : 1e30f;
+        }
+        memcpy(r.axis, n.cone, 12); r.cos_t = n.cos_t; r.sin_t = n.sin_t;
+        r.skip = (int32_t)out.size();
+        r.meta = (depth & 0xff) | (leaf ? 0x100 : 0) | (n.use_cone ? 0x200 : 0) | (leaf ? (int32_t)(n.b - n.a) << 16 : 0);
+        r.first = leaf ? (int32_t)n.a : 0;
+    }
+};
+
+int depth_of(const BNode& n) { return n.l ? 1 + std::max(depth_of(*n.l), depth_of(*n.r)) : 0; }
+
+}  // namespace
+
+// `flat` already holds the reference trees (rt_build_flat_scene).  Fills flat->bvh_* .
+int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err) {
+    const std::vector<DevNode>& ref = flat->nodes[7];
+    const size_t nn = ref.size();
+    // parents of the reference's nodes (pre-order + skip pointers -> a stack walk)
+    flat->ref_parent.assign(nn, -1);
+    {
+        std::vector<int32_t> stack;
+        for (size_t i = 0; i < nn; ++i) {
+            while (!stack.empty() && ref[(size_t)stack.back()].skip <= (int32_t)i) stack.pop_back();
+            flat->ref_parent[i] = stack.empty() ? -1 : stack.back();
+            if (!(ref[i].meta & 0x100)) stack.push_back((int32_t)i);
+        }
+    }
+    // per reference node: the intersection of the boxes on its chain (its own and its ancestors').  The boxes are
+    // nested only up to the rounding of center -+ extend / 2, so this is the one box inside all of them; a leaf
+    // whose intersection is inverted on some axis (flat boxes) gets NaN = "walk the chain".
+    flat->ref_chain_box.assign(nn * 6, 0.f);
+    for (size_t i = 0; i < nn; ++i) {
+        float* c = &flat->ref_chain_box[i * 6];
+        const int32_t p = flat->ref_parent[i];
+        for (int k = 0; k < 3; ++k) {
+            c[k] = p < 0 ? ref[i].lo[k] : std::max(ref[i].lo[k], flat->ref_chain_box[(size_t)p * 6 + k]);
+            c[3 + k] = p < 0 ? ref[i].hi[k] : std::min(ref[i].hi[k], flat->ref_chain_box[(size_t)p * 6 + 3 + k]);
+        }
+    }
+    for (size_t i = 0; i < nn; ++i) {
+        float* c = &flat->ref_chain_box[i * 6];
+        if ((ref[i].meta & 0x100) && (c[0] > c[3] || c[1] > c[4] || c[2] > c[5])) c[0] = std::nanf("");
+    }
+    // per triangle: the reference leaves that hold it, in the reference's visit order (rank)
+    struct Ref { int32_t prim, rank, leaf; };
+    std::vector<Ref> refs;
+    refs.reserve(flat->leaf_tris.size());
+    for (size_t i = 0; i < nn; ++i)
+        if (ref[i].meta & 0x100)
+            for (int32_t k = 0; k < ref[i].leaf_count; ++k) {
+                const DevLeafTri& t = flat->leaf_tris[(size_t)(ref[i].leaf_first + k)];
+                refs.push_back(Ref{t.prim, t.rank, (int32_t)i});
+            }
+    std::sort(refs.begin(), refs.end(), [](const Ref& x, const Ref& y) { return x.prim < y.prim || (x.prim == y.prim && x.rank < y.rank); });
+    BvhBuilder B;
+    B.d = d;
+    std::vector<int32_t> first_of((size_t)d->nprim, -1), count_of((size_t)d->nprim, 0);
+    flat->bvh_ref_leaf.resize(refs.size());
+    for (size_t i = 0; i < refs.size(); ++i) {
+        flat->bvh_ref_leaf[i] = DevRefLeaf{refs[i].leaf, refs[i].rank};
+        if (first_of[(size_t)refs[i].prim] < 0) { first_of[(size_t)refs[i].prim] = (int32_t)i; B.idx.push_back(refs[i].prim); }
+        count_of[(size_t)refs[i].prim]++;
+    }
+    const int64_t nt = (int64_t)B.idx.size();
+    B.gm_of.assign((size_t)d->nprim, 0.f);
+    for (int32_t p : B.idx) {
+        const float* f = d->prims[p].f;
+        float l1 = 0.f, l2 = 0.f;
+        for (int k = 0; k < 3; ++k) { const float a = f[3 + k] - f[k], b = f[6 + k] - f[k]; l1 += a * a; l2 += b * b; }
+        B.gm_of[(size_t)p] = std::sqrt(l1) * std::sqrt(l2);
+    }
+    for (int o = 0; o < 8; ++o) flat->bvh_nodes[o].clear();
+    flat->bvh_tris.clear(); flat->bvh_tri_ref.clear();
+    if (nt == 0) return RT_OK;
+    const int nth = rt_host_threads();
+    B.par_min = nth > 1 ? std::max<size_t>((size_t)1 << 15, (size_t)nt / (size_t)(4 * nth)) : SIZE_MAX;
+    BNode root; root.a = 0; root.b = nt;
+    B.build(root);
+    if (depth_of(root) + 1 > 250) { *err = "BVH deeper than 250 levels"; return RT_E_LIMIT; }
+    // triangle records in the order of idx (a leaf is a contiguous run)
+    flat->bvh_tris.resize((size_t)nt); flat->bvh_tri_ref.resize((size_t)nt * 2);
+    for (int64_t j = 0; j < nt; ++j) {
+        const int32_t p = B.idx[(size_t)j];
+        const float* f = d->prims[p].f;
+        DevLeafTri t{};
+        for (int k = 0; k < 3; ++k) { t.v0[k] = f[k]; t.e1[k] = f[3 + k] - f[k]; t.e2[k] = f[6 + k] - f[k]; }
+        t.prim = p;
+        t.flags = ((double)d->materials[d->prim_material[p]].refract > 0.1) ? RT_PF_SKIP_SHADOW : 0;
+        t.rank = (int32_t)j;                                      // index into bvh_tri_ref
+        flat->bvh_tris[(size_t)j] = t;
+        flat->bvh_tri_ref[(size_t)j * 2] = first_of[(size_t)p]; flat->bvh_tri_ref[(size_t)j * 2 + 1] = count_of[(size_t)p];
+    }
+    if (nth > 1 && nt > 4096) {
+        std::vector<std::thread> th;
+        for (int o = 0; o < 8; ++o) th.emplace_back([&B, &root, flat, o] { B.emit(root, 0, o, flat->bvh_nodes[o]); });
+        for (std::thread& t : th) t.join();
+    } else {
+        for (int o = 0; o < 8; ++o) B.emit(root, 0, o, flat->bvh_nodes[o]);
+    }
+    if (flat->bvh_nodes[0].size() > (size_t)INT32_MAX / 2) { *err = "BVH exceeds 2^30 nodes"; return RT_E_LIMIT; }
+    return RT_OK;
+}

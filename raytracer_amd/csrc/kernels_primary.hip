@@ -13,7 +13,8 @@
 
 #define PRIMARY_MAX_LIGHTS 32
 
-extern "C" __global__ void __launch_bounds__(256)
+template <bool BVH>
+__global__ void __launch_bounds__(256)
 k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntiles, float eps_f,
                float ambient_intensity, float bgr, float bgg, float bgb, uint8_t* __restrict__ rgb8,
                int32_t* __restrict__ hit_ids, float* __restrict__ radiance_out, unsigned int* __restrict__ wave_pairs) {
@@ -31,7 +32,8 @@ k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles
 
     Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
     bool occ = false;
-    traverse_fast<false>(sc, r, inside, eps_f, 0.f, false, best, occ);
+    if (BVH) traverse_bvh<false>(sc, r, inside, eps_f, 0.f, false, best, occ);
+    else traverse_fast<false>(sc, r, inside, eps_f, 0.f, false, best, occ);
     loose_prims<false>(sc, r, inside, eps_f, 0.f, false, best, occ);
     const bool hit = inside && best.prim >= 0;
 
@@ -56,7 +58,8 @@ k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles
         const Rayf sr = {s6[0], s6[1], s6[2], s6[3], s6[4], s6[5]};
         Closest dummy; dummy.len = 1e9f; dummy.prim = -1; dummy.px = dummy.py = dummy.pz = 0.f; dummy.rank = 0x7fffffff;
         bool o = false;
-        traverse_fast<true>(sc, sr, hit, eps_f, 0.f, false, dummy, o);
+        if (BVH) traverse_bvh<true>(sc, sr, hit, eps_f, 0.f, false, dummy, o);
+        else traverse_fast<true>(sc, sr, hit, eps_f, 0.f, false, dummy, o);
         loose_prims<true>(sc, sr, hit, eps_f, 0.f, false, dummy, o);
         occluded |= (o ? 1u : 0u) << l;
     }
@@ -81,11 +84,15 @@ int rtk_primary_only_max_lights() { return PRIMARY_MAX_LIGHTS; }
 // d_wave_pairs: 2 unsigned per micro-tile (= per wave)
 hipError_t rtk_primary_only(const DevSceneView& sc, const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float eps_f,
                             float ambient, const float bg[3], uint8_t* d_rgb8, int32_t* d_hit_ids, float* d_radiance,
-                            unsigned int* d_wave_pairs, hipStream_t st) {
+                            unsigned int* d_wave_pairs, int bvh, hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
     static const int block = [] { const char* e = getenv("RT_PRIMARY_BLOCK"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();
     const unsigned grid = (unsigned)((ntiles * 64 + block - 1) / block);
-    hipLaunchKernelGGL(k_primary_only, dim3(grid), dim3(block), 0, st, sc, cam, d_tiles, ntiles, eps_f, ambient, bg[0], bg[1], bg[2],
-                       d_rgb8, d_hit_ids, d_radiance, d_wave_pairs);
+    if (bvh)
+        hipLaunchKernelGGL(k_primary_only<true>, dim3(grid), dim3(block), 0, st, sc, cam, d_tiles, ntiles, eps_f, ambient, bg[0], bg[1],
+                           bg[2], d_rgb8, d_hit_ids, d_radiance, d_wave_pairs);
+    else
+        hipLaunchKernelGGL(k_primary_only<false>, dim3(grid), dim3(block), 0, st, sc, cam, d_tiles, ntiles, eps_f, ambient, bg[0], bg[1],
+                           bg[2], d_rgb8, d_hit_ids, d_radiance, d_wave_pairs);
     return hipGetLastError();
 }

@@ -99,6 +99,42 @@ k_trace_any_lane(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t
     if (inb) occluded[i] = occ ? 1 : 0;
 }
 
+// the build's own hierarchy instead of the reference's tree (trace_device.h: traverse_bvh)
+extern "C" __global__ void __launch_bounds__(256)
+k_trace_closest_bvh(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                    int64_t n, float eps_f, rt_hit* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    const bool valid = inb && (active == nullptr || active[i] >= 0);
+    Rayf r = {0, 0, 0, 0, 0, 1};
+    if (valid) r = load_ray(rays, i);
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+    bool occ = false;
+    traverse_bvh<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
+    loose_prims<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
+    if (inb) {
+        float* o = reinterpret_cast<float*>(out + i);
+        reinterpret_cast<int32_t*>(o)[0] = best.prim;
+        o[1] = best.len; o[2] = best.px; o[3] = best.py; o[4] = best.pz;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_trace_any_bvh(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i < n;
+    const bool valid = inb && (active == nullptr || active[i] >= 0);
+    Rayf r = {0, 0, 0, 0, 0, 1};
+    float tm = 0.f;
+    if (valid) { r = load_ray(rays, i); if (tmax) tm = tmax[i]; }
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+    bool occ = false;
+    traverse_bvh<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
+    loose_prims<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
+    if (inb) occluded[i] = occ ? 1 : 0;
+}
+
 // Measurement only (bench.py, tests): the same traversal with per-lane work counters.  out4[0] box tests,
 // [1] triangle records read by a lane that was inside the leaf (screening or exact), [2] exact
 // reference-sequence triangle tests, [3] node / triangle record fetches summed over lanes (a wave-uniform
@@ -117,11 +153,13 @@ k_trace_work(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __
     bool occ = false;
     Work w = {0, 0, 0, 0};
     if (any) {
-        if (fast) traverse_fast<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
+        if (fast == 3) traverse_bvh<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
+        else if (fast) traverse_fast<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
         else traverse<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
         loose_prims<true, true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ, &w);
     } else {
-        if (fast) traverse_fast<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
+        if (fast == 3) traverse_bvh<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
+        else if (fast) traverse_fast<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
         else traverse<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
         loose_prims<false, true>(sc, r, valid, eps_f, 0.f, false, best, occ, &w);
     }
@@ -216,6 +254,10 @@ static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + b
 hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
                              float eps_f, int fast, rt_hit* d_out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
+    if (fast == 3) {
+        hipLaunchKernelGGL(k_trace_closest_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
+        return hipGetLastError();
+    }
     if (fast == 2) {
         hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
         return hipGetLastError();
@@ -227,6 +269,10 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
                          int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st) {
     if (n <= 0) return hipSuccess;
+    if (fast == 3) {
+        hipLaunchKernelGGL(k_trace_any_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+        return hipGetLastError();
+    }
     if (fast == 2) {
         hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
         return hipGetLastError();

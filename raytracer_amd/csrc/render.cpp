@@ -101,7 +101,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
 
     // BASELINE configuration 2 (primary + shadow rays, one centre sample) has a kernel of its own
-    const bool fused = s->fused_primary && p->primary_only && !drt && s->fast == 1 && !(stats && p->count_work) &&
+    const bool fused = s->fused_primary && p->primary_only && !drt && (s->fast == 1 || s->fast == 3) && !(stats && p->count_work) &&
                        L <= rtk_primary_only_max_lights();
     int64_t passes = 0;
     std::vector<int64_t> pass_n;      // rays of every pass (RT_TRACE_PASSES=1 prints them with the kernel times)
@@ -121,7 +121,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         ++passes; pass_n.push_back(n0);
         RTCHK(mark());
         HIPCHK(rtk_primary_only(s->view, *cam, c_tiles, ctiles, s->eps_f, p->ambient_intensity, p->background, d_rgb8, d_hit_ids,
-                                s->d_radiance_out, (unsigned int*)pairs, st), "k_primary_only");
+                                s->d_radiance_out, (unsigned int*)pairs, s->fast == 3 ? 1 : 0, st), "k_primary_only");
         RTCHK(mark()); RTCHK(mark()); RTCHK(mark());
         HIPCHK(rtk_reduce_pairs((const unsigned int*)pairs, nblocks, d_ctr, st), "k_reduce_pairs");
         continue;
@@ -160,14 +160,14 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
         }
         RTCHK(mark());
-        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, (s->fast == 1 && depth >= s->lane_depth) ? 2 : s->fast, (rt_hit*)hits, st), "k_trace_closest");
+        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast, (rt_hit*)hits, st), "k_trace_closest");
         RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
                                (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, q_code, p->seed, p->light_radius, st), "k_shade_flags");
         RTCHK(mark());
         if (L > 0)
-            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, (s->fast == 1 && depth >= s->lane_depth) ? 2 : s->fast, (uint8_t*)occ, st), "k_trace_any");
+            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast, (uint8_t*)occ, st), "k_trace_any");
         RTCHK(mark());
         if (d_work) {
             HIPCHK(rtk_trace_work(s->view, q_rays, q_pix, nullptr, n, s->eps_f, s->fast, 0, d_work, st), "k_trace_work");

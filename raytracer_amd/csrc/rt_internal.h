@@ -57,6 +57,24 @@ static_assert(sizeof(DevLeafGroup) == 64, "DevLeafGroup must be 64 bytes");
 #define RT_PF_SKIP_SHADOW 1   // refract > 0.1
 #define RT_PF_SPHERE      2
 
+// The build's own hierarchy over the tree triangles (bvh_build.cpp): a binary BVH in pre-order with skip
+// pointers, eight layouts like the reference nodes.  A node carries what the group test of 4.1b needs to inflate its
+// box soundly: the largest |e1||e2| and the smallest |e1 x e2| of its triangles, and (small subtrees) their normal cone.
+struct DevBvhNode {         // 64 B
+    float lo[3], hi[3];     // bounding box of the subtree's triangles
+    float slack;            // box inflation per unit of reach for a unit-length ray when nothing bounds |det| but the
+                            // reference's cut-off (trace_device.h: lateral_slack with |dir| <= 1.001), + 2e-5 for the slabs
+    float cone_k;           // with the cone: the inflation per unit reach is cone_k / cos(angle + cone), if smaller
+    float axis[3];          // normal cone: axis, cos, sin of the half angle (rounded outwards); valid if meta & 0x200
+    float cos_t, sin_t;
+    int32_t skip;           // next node when the subtree is not entered
+    int32_t meta;           // depth | leaf << 8 | cone << 9 | (leaf: triangle count) << 16
+    int32_t first;          // leaf: first record in bvh_tris
+};
+static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode must be 64 bytes");
+struct DevRefLeaf { int32_t leaf; int32_t rank; };   // a reference leaf (index in layout 7) holding a triangle, and the
+                                                     // reference's visit rank of that record
+
 struct DevLoose {           // 48 B: a primitive tested one by one after the trees
     float a[9];             // triangle: v0,e1,e2   sphere: center(3), radius, unused
     int32_t prim;
@@ -98,6 +116,13 @@ struct DevSceneView {       // passed by value to kernels
     const DevLeafTri* leaf_tris;
     const DevLeafGroup* leaf_groups;
     const DevLoose* loose; int32_t nloose;
+    // the build's own hierarchy; nbvh = 0: none
+    const DevBvhNode* bvh_oct[8]; int32_t nbvh;
+    const DevLeafTri* bvh_tris;         // every tree triangle once; .rank = its index t into bvh_tri_ref
+    const int32_t* bvh_tri_ref;         // [t][2]: first, count into bvh_ref_leaf
+    const DevRefLeaf* bvh_ref_leaf;     // the reference leaves holding triangle t, by rising rank
+    const int32_t* ref_parent;          // parent of reference node i (layout 7), -1 = a root
+    const float* ref_chain_box;         // [node][6]: lo, hi of the intersection of the boxes on node i's chain (NaN lo[0]: none)
     const float* prim_normal;   // [nprim][3] fixed-point normal (triangles)
     const int32_t* prim_material;
     const uint8_t* prim_type;
@@ -120,6 +145,12 @@ struct HostFlatScene {
     std::vector<DevLeafTri> leaf_tris;
     std::vector<DevLeafGroup> leaf_groups;
     std::vector<DevLoose> loose;
+    std::vector<DevBvhNode> bvh_nodes[8];      // bvh_build.cpp
+    std::vector<DevLeafTri> bvh_tris;
+    std::vector<int32_t> bvh_tri_ref;
+    std::vector<DevRefLeaf> bvh_ref_leaf;
+    std::vector<int32_t> ref_parent;
+    std::vector<float> ref_chain_box;
     std::vector<float> prim_normal;
     std::vector<float> prim_geom;
     int64_t kd_nodes_built = 0;
@@ -129,6 +160,7 @@ struct HostFlatScene {
 
 // scene_build.cpp
 int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string* err);
+int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err);      // bvh_build.cpp
 // photon_build.cpp
 void rt_photon_balance_host(rt_photon* photons, int64_t n);
 void rt_photon_product_order(const rt_photon* heap, int64_t n, std::vector<int32_t>& src, std::vector<int8_t>& plane);
@@ -175,7 +207,7 @@ hipError_t rtk_reduce_pairs(const unsigned int* block_pairs, int64_t nblocks, un
 int rtk_primary_only_max_lights();
 hipError_t rtk_primary_only(const DevSceneView& sc, const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float eps_f,
                             float ambient, const float bg[3], uint8_t* d_rgb8, int32_t* d_hit_ids, float* d_radiance,
-                            unsigned int* d_block_pairs, hipStream_t st);
+                            unsigned int* d_block_pairs, int bvh, hipStream_t st);
 hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
                         uint8_t* rgb8, hipStream_t st);
 hipError_t rtk_copy_radiance(const int32_t* pix0, int64_t n, const float* accum, float* out, hipStream_t st);

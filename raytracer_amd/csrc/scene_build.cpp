@@ -208,6 +208,9 @@ struct Flattener {
             float ext = 0.f;
             for (int k = 0; k < 3; ++k) ext = std::max(ext, g.hi[k] - g.lo[k]);
             g.pad[0] = (2.0f * gm * 4.0f > 0.1f * ext) ? 1.0f : 0.0f;
+            // what the group adds to a ray's reach (trace_device.h: lateral_slack): its triangles may stick out of the
+            // leaf's box by the group's L1 diagonal, plus 0.44 (|e1| + |e2|) <= 0.88 of that diagonal
+            g.pad[1] = 1.9f * ((g.hi[0] - g.lo[0]) + (g.hi[1] - g.lo[1]) + (g.hi[2] - g.lo[2]));
             margin = std::max(margin, gm);
             n.groups.push_back(g);
         }

@@ -23,22 +23,23 @@ struct Rayf { float ox, oy, oz, dx, dy, dz; };
 __device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 
 // KDNode::HitTest, hw4.cpp:281-328.  lo/hi are center -/+ extend/2.0f.
-__device__ __forceinline__ bool box_test(const DevNode& n, const Rayf& r) {
-    float tmin = (n.lo[0] - r.ox) / r.dx;
-    float tmax = (n.hi[0] - r.ox) / r.dx;
+__device__ __forceinline__ bool box_test_b(const float* __restrict__ lo, const float* __restrict__ hi, const Rayf& r) {
+    float tmin = (lo[0] - r.ox) / r.dx;
+    float tmax = (hi[0] - r.ox) / r.dx;
     if (tmin > tmax) { float t = tmin; tmin = tmax; tmax = t; }
-    float tymin = (n.lo[1] - r.oy) / r.dy;
-    float tymax = (n.hi[1] - r.oy) / r.dy;
+    float tymin = (lo[1] - r.oy) / r.dy;
+    float tymax = (hi[1] - r.oy) / r.dy;
     if (tymin > tymax) { float t = tymin; tymin = tymax; tymax = t; }
     if ((tmin > tymax) || (tymin > tmax)) return false;
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmax) tmax = tymax;
-    float tzmin = (n.lo[2] - r.oz) / r.dz;
-    float tzmax = (n.hi[2] - r.oz) / r.dz;
+    float tzmin = (lo[2] - r.oz) / r.dz;
+    float tzmax = (hi[2] - r.oz) / r.dz;
     if (tzmin > tzmax) { float t = tzmin; tzmin = tzmax; tzmax = t; }
     if ((tmin > tzmax) || (tzmin > tmax)) return false;
     return true;
 }
+__device__ __forceinline__ bool box_test(const DevNode& n, const Rayf& r) { return box_test_b(n.lo, n.hi, r); }
 
 // Triangle::IntersectionTest, hw4.cpp:171-231.  a = {v0, edge1, edge2}.
 // eps_f = smallest float above the reference's double `epsilon` 1e-6, so
@@ -204,6 +205,25 @@ __device__ __forceinline__ RayAux ray_aux(const Rayf& r) {
     return a;
 }
 
+// How far outside a triangle's true extent the (exact) ray may pass its plane and still be accepted by the
+// reference's rounded u / v tests, per unit of `reach` >= |orig - v0| + 0.44 (|e1| + |e2|)  (DESIGN 4.1b):
+//   |u_true - u| <= (E_du + u E_det) / |det_true|,  E_du <= 7.5 eps |tvec| |dir| |e2|,  E_det <= 6.6 eps |dir| |e1| |e2|
+// (same for v), so the plane point is within 15 eps |dir| gm reach / |det_true| of the triangle, gm = |e1| |e2|.
+// |det_true| >= the reference's cut-off (hw4.cpp:209) less E_det, and >= |e1 x e2| |dir . n| bounded through the
+// normal cone.  15 eps = 8.9e-7 is applied as 1.2e-6; no bound (a huge value) when neither floor is positive.
+__device__ __forceinline__ float lateral_slack(float gm, float area2_min, bool cone, const float* __restrict__ axis,
+                                               float cos_t, float sin_t, const Rayf& r, const RayAux& aux, float eps_f) {
+    const float dg = aux.dlen * gm;
+    float D = eps_f - 4.0e-7f * dg;
+    if (cone) {
+        const float c = __builtin_fabsf(r.dx * axis[0] + r.dy * axis[1] + r.dz * axis[2]) * aux.rlen;
+        const float cc = __builtin_fminf(c, 1.0f);
+        const float lb = cc * cos_t - sqrt_rn(1.0f - cc * cc) * sin_t;      // cos(angle + cone) <= |dir . n| / |dir|
+        D = __builtin_fmaxf(D, area2_min * lb * aux.dlen * 0.999f);
+    }
+    return D > 1e-12f ? 1.2e-6f * dg * __builtin_amdgcn_rcpf(D) : 1e30f;      // 1.2e-6 leaves a third of room over 15 eps
+}
+
 // returns the reference's HitTest boolean; enter/exit are slab parameters good to ~1e-6 relative
 __device__ __forceinline__ bool box_fast(const DevNode& n, const Rayf& r, const RayAux& a, float& enter, float& exit) {
     const float x0 = (n.lo[0] - r.ox) * a.rx, x1 = (n.hi[0] - r.ox) * a.rx;
@@ -270,18 +290,10 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
                 bool ghit = hit;
                 if (COUNT) { w->fetch += 1; if (hit) w->box += 1; }
                 if (hit && aux.plain) {
-                    // slack: 4 x the first-order bound 5 eps |e1||e2| (|tvec| + |e|) / |det| on how far outside a triangle
-                    // (and how far off in t) a hit the reference accepts can be.  |det| >= |e1 x e2| |dir . n|, bounded from
-                    // below through the group's normal cone; never below the reference's own cut-off 1e-6 (hw4.cpp:209).
-                    float lat = 2.0f * gp->gm;                                 // |det| >= 1e-6: 1.2e-6 gm / 1e-6, rounded up
-                    if (gp->pad[0] != 0.0f) {                                  // wave-uniform
-                        const float c = __builtin_fabsf(r.dx * gp->axis[0] + r.dy * gp->axis[1] + r.dz * gp->axis[2]) * aux.rlen;
-                        const float cc = __builtin_fminf(c, 1.0f);
-                        const float lb = cc * gp->cos_t - sqrt_rn(1.0f - cc * cc) * gp->sin_t; // cos(angle + cone) <= |dir . n| / |dir|
-                        const float detmin = __builtin_fmaxf(gp->area2_min * lb * aux.dlen * 0.999f, 1e-6f);
-                        lat = 1.2e-6f * gp->gm / detmin;
-                    }
-                    const float sl = (lat + 2e-5f) * reach + 1e-6f;
+                    // lateral slack (lateral_slack above); the group's own extent joins the reach: its triangles may
+                    // stick out of the leaf's box
+                    const float lat = lateral_slack(gp->gm, gp->area2_min, gp->pad[0] != 0.0f, gp->axis, gp->cos_t, gp->sin_t, r, aux, eps_f);
+                    const float sl = (lat + 2e-5f) * (reach + gp->pad[1]) + 1e-6f;
                     const float x0 = (gp->lo[0] - sl - r.ox) * aux.rx, x1 = (gp->hi[0] + sl - r.ox) * aux.rx;
                     const float y0 = (gp->lo[1] - sl - r.oy) * aux.ry, y1 = (gp->hi[1] + sl - r.oy) * aux.ry;
                     const float z0 = (gp->lo[2] - sl - r.oz) * aux.rz, z1 = (gp->hi[2] + sl - r.oz) * aux.rz;
@@ -384,15 +396,8 @@ __device__ __forceinline__ void traverse_lane(const DevSceneView& sc, const Rayf
                 const DevLeafGroup gp = sc.leaf_groups[g];
                 bool ghit = true;
                 if (aux.plain) {
-                    float lat = 2.0f * gp.gm;
-                    if (gp.pad[0] != 0.0f) {
-                        const float c = __builtin_fabsf(r.dx * gp.axis[0] + r.dy * gp.axis[1] + r.dz * gp.axis[2]) * aux.rlen;
-                        const float cc = __builtin_fminf(c, 1.0f);
-                        const float lb = cc * gp.cos_t - sqrt_rn(1.0f - cc * cc) * gp.sin_t;
-                        const float detmin = __builtin_fmaxf(gp.area2_min * lb * aux.dlen * 0.999f, 1e-6f);
-                        lat = 1.2e-6f * gp.gm / detmin;
-                    }
-                    const float sl = (lat + 2e-5f) * reach + 1e-6f;
+                    const float lat = lateral_slack(gp.gm, gp.area2_min, gp.pad[0] != 0.0f, gp.axis, gp.cos_t, gp.sin_t, r, aux, eps_f);
+                    const float sl = (lat + 2e-5f) * (reach + gp.pad[1]) + 1e-6f;
                     const float x0 = (gp.lo[0] - sl - r.ox) * aux.rx, x1 = (gp.hi[0] + sl - r.ox) * aux.rx;
                     const float y0 = (gp.lo[1] - sl - r.oy) * aux.ry, y1 = (gp.hi[1] + sl - r.oy) * aux.ry;
                     const float z0 = (gp.lo[2] - sl - r.oz) * aux.rz, z1 = (gp.hi[2] + sl - r.oz) * aux.rz;
@@ -472,6 +477,150 @@ __device__ __forceinline__ void traverse_lane(const DevSceneView& sc, const Rayf
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BVH traversal: the walk of traverse_fast over the build's OWN hierarchy (bvh_build.cpp: every tree
+// triangle once, <= RT_GROUP per leaf, boxes that follow the geometry) instead of the reference's KD-tree.
+//  * every node is tested like a leaf group of 4.1b: its box inflated by the rounding slack of the triangles below
+//    it, skipped when missed, behind the origin or beyond the best hit;
+//  * a triangle is tested with the reference's exact sequence (same screening as traverse_fast), so it is accepted
+//    or not, and gets its len, exactly as the reference would -- IF the reference tests it for this ray, i.e. if
+//    it sits in a reference leaf whose whole chain of boxes passes KDNode::HitTest.  reachable_rank decides that per
+//    ACCEPTED hit (one or two per ray), over the reference leaves that hold the triangle, in the reference's visit
+//    order.  HitTest's quotients (bound - orig) / dir are monotone in the bound, so a ray with no zero direction
+//    component (no NaN quotient) that passes HitTest on a box INSIDE every box of the chain passes every test of the
+//    chain: bvh_build.cpp keeps that box per leaf (the chain's boxes are nested up to rounding, so it is the leaf's
+//    box give or take an ulp).  The rare ray that misses it walks the chain (traverse_bvh takes no ray with a zero
+//    component).  Returned: the visit rank of the first reachable record, which
+//    is also the tie-break key among equal len.
+// Rays with a zero or non-finite component, or not of unit length (|dir| within 1e-3 of 1), take traverse_fast with
+// their whole wave.
+__device__ __forceinline__ int reachable_rank(const DevSceneView& sc, int tref, const Rayf& r) {
+    const int first = sc.bvh_tri_ref[2 * tref], cnt = sc.bvh_tri_ref[2 * tref + 1];
+    for (int j = 0; j < cnt; ++j) {
+        const DevRefLeaf rl = sc.bvh_ref_leaf[first + j];
+        const float* __restrict__ cb = sc.ref_chain_box + 6 * (int64_t)rl.leaf;
+        if (cb[0] == cb[0] && box_test_b(cb, cb + 3, r)) return rl.rank;
+        bool ok = true;
+        for (int k = rl.leaf; k >= 0 && ok; k = sc.ref_parent[k]) ok = box_test(sc.nodes[k], r);
+        if (ok) return rl.rank;
+    }
+    return 0x7fffffff;
+}
+
+template <bool ANY, bool COUNT = false>
+__device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf& r, bool valid,
+                                             float eps_f, float tmax, bool use_tmax,
+                                             Closest& best, bool& occluded, Work* w = nullptr) {
+    const RayAux aux = ray_aux(r);
+    const bool fit = aux.plain && aux.dlen > 0.999f && aux.dlen < 1.001f;
+    if (__ballot(valid && !fit) != 0ull || sc.nbvh == 0) { traverse_fast<ANY, COUNT>(sc, r, valid, eps_f, tmax, use_tmax, best, occluded, w); return; }
+    int fail = valid ? RT_ALIVE : RT_DEAD;
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    const int oct_l = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
+    const int oct = __builtin_amdgcn_readlane(oct_l, __builtin_ctzll(vm));
+    const DevBvhNode* __restrict__ nodes = sc.bvh_oct[oct];
+    const float far_limit = ANY ? (use_tmax ? tmax : 1e9f) : 0.f;
+    const int nn = sc.nbvh;
+    float reach = 0.f;
+    {   // |orig - v0| + 0.44 (|e1| + |e2|) for every triangle: origin to the root box's centre + 3 x its half diagonal
+        const DevBvhNode rt = nodes[0];
+        const float cx = 0.5f * (rt.lo[0] + rt.hi[0]) - r.ox, cy = 0.5f * (rt.lo[1] + rt.hi[1]) - r.oy, cz = 0.5f * (rt.lo[2] + rt.hi[2]) - r.oz;
+        const float hx = rt.hi[0] - rt.lo[0], hy = rt.hi[1] - rt.lo[1], hz = rt.hi[2] - rt.lo[2];
+        reach = 1.001f * (sqrt_rn(cx * cx + cy * cy + cz * cz) + 1.5f * sqrt_rn(hx * hx + hy * hy + hz * hz)) + 1e-6f;
+    }
+    // slabs as one fused multiply-add per plane, (bound -+ sl) * (1/d) - orig * (1/d): against the subtraction first, the
+    // plane moves by <= 3 eps (|orig| + |bound|), which the constant part of the inflation covers
+    const float px = -(r.ox * aux.rx), py = -(r.oy * aux.ry), pz = -(r.oz * aux.rz);
+    const float sl0 = 1e-6f + 1e-6f * (__builtin_fabsf(r.ox) + __builtin_fabsf(r.oy) + __builtin_fabsf(r.oz)) + 1e-6f * reach;
+    int i = 0;
+    while (i < nn) {
+        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
+        const DevBvhNode nd = nodes[i];                   // wave-uniform address
+        const int depth = nd.meta & 0xff;
+        if (fail >= depth) fail = RT_ALIVE;
+        bool hit = false;
+        if (COUNT) w->fetch += 1;
+        if (fail == RT_ALIVE) {
+            if (COUNT) w->box += 1;
+            float lat = nd.slack;
+            if (nd.meta & 0x200) {                           // wave-uniform
+                const float c = __builtin_fabsf(r.dx * nd.axis[0] + r.dy * nd.axis[1] + r.dz * nd.axis[2]) * aux.rlen;
+                const float cc = __builtin_fminf(c, 1.0f);
+                const float lb = cc * nd.cos_t - sqrt_rn(1.0f - cc * cc) * nd.sin_t;     // cos(angle + cone) <= |dir . n| / |dir|
+                if (lb > 0.0f) lat = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
+            }
+            const float sl = __builtin_fmaf(lat, reach, sl0);
+            const float x0 = __builtin_fmaf(nd.lo[0] - sl, aux.rx, px), x1 = __builtin_fmaf(nd.hi[0] + sl, aux.rx, px);
+            const float y0 = __builtin_fmaf(nd.lo[1] - sl, aux.ry, py), y1 = __builtin_fmaf(nd.hi[1] + sl, aux.ry, py);
+            const float z0 = __builtin_fmaf(nd.lo[2] - sl, aux.rz, pz), z1 = __builtin_fmaf(nd.hi[2] + sl, aux.rz, pz);
+            const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+            const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+            const float limit = ANY ? far_limit : best.len;
+            hit = !(ex < en || ex * aux.dlen < 0.0f || en * aux.dlen > limit);
+            if (!hit) fail = depth;
+        }
+        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
+        if (nd.meta & 0x100) {
+            const int t0 = nd.first, t1 = nd.first + (nd.meta >> 16);
+            for (int ti = t0; ti < t1; ++ti) {
+                const DevLeafTri* __restrict__ t = sc.bvh_tris + ti;                // wave-uniform
+                if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+                const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
+                const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
+                const float pvx = r.dy * e2z - r.dz * e2y;
+                const float pvy = r.dz * e2x - r.dx * e2z;
+                const float pvz = r.dx * e2y - r.dy * e2x;
+                const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+                if (COUNT) { w->fetch += 1; if (hit) w->tri += 1; }
+                bool cand = hit && !(__builtin_fabsf(det) < eps_f);
+                const float ri = __builtin_amdgcn_rcpf(det);
+                const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
+                const float du = tx * pvx + ty * pvy + tz * pvz;
+                const float ua = du * ri;
+                cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
+                if (__ballot(cand) == 0ull) continue;
+                const float qx = ty * e1z - tz * e1y;
+                const float qy = tz * e1x - tx * e1z;
+                const float qz = tx * e1y - ty * e1x;
+                const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
+                const float dt = e2x * qx + e2y * qy + e2z * qz;
+                const float va = dv * ri, ta = dt * ri;
+                cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
+                if (__ballot(cand) == 0ull) continue;
+                if (cand) {                                                          // hw4.cpp:211-230, exactly
+                    if (COUNT) w->exact += 1;
+                    const float detInv = 1.0f / det;
+                    const float u = du * detInv;
+                    if (!(u < 0 || u > 1.0f)) {
+                        const float v = dv * detInv;
+                        if (!(v < 0 || u + v > 1.0f)) {
+                            const float tt = dt * detInv;
+                            if (!(tt < 0)) {
+                                const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
+                                const float len = dist_to(r, px, py, pz);
+                                if (ANY) {
+                                    if (len < far_limit && len >= sc.tol_f && reachable_rank(sc, t->rank, r) != 0x7fffffff) {
+                                        occluded = true; fail = RT_DEAD; hit = false;
+                                    }
+                                } else if (len <= best.len && len >= sc.tol_f &&
+                                           (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
+                                    const int rr = reachable_rank(sc, t->rank, r);
+                                    if (rr != 0x7fffffff && (len < best.len || rr < best.rank)) {
+                                        best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                                        best.rank = rr;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        i = i + 1;
     }
 }
 

@@ -198,7 +198,7 @@ class Scene:
         """"strict" (reference order, no culling) or "fast" (default)."""
         abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_TRAVERSAL,
                                              {"strict": abi.RT_TRAVERSAL_STRICT, "fast": abi.RT_TRAVERSAL_FAST,
-                                              "lane": abi.RT_TRAVERSAL_LANE}[mode]))
+                                              "lane": abi.RT_TRAVERSAL_LANE, "bvh": abi.RT_TRAVERSAL_BVH}[mode]))
 
     def knn_stats(self, on=None):
         """work counters of the wave-shared radiance-estimate kernels (include/rt_hip.h, RT_OPT_KNN_STATS): on=True zeroes and

@@ -30,7 +30,7 @@ def _assert_rgb_close(got, want):
     return int((d > 0).sum())
 
 
-@pytest.fixture(scope="module", params=["fast", "strict", "lane"])
+@pytest.fixture(scope="module", params=["fast", "strict", "lane", "bvh"])
 def gscene(monkey_sd, request):
     s = host.Scene(monkey_sd)
     s.set_traversal(request.param)

@@ -47,7 +47,7 @@ def _assert_hits_equal(g, o):
     assert np.all(g["len"][~hit] == np.float32(1e9))
 
 
-@pytest.fixture(scope="module", params=["fast", "strict", "lane"])
+@pytest.fixture(scope="module", params=["fast", "strict", "lane", "bvh"])
 def monkey(monkey_sd, request):
     g = host.Scene(monkey_sd)
     g.set_traversal(request.param)
@@ -141,7 +141,7 @@ def _soup_scene(n, seed, nobj=3, big_floor=True):
                      view=np.array([0, 0, 1], np.float32), fov=45.0, resx=64, resy=64)
 
 
-@pytest.mark.parametrize("mode", ["fast", "strict", "lane"])
+@pytest.mark.parametrize("mode", ["fast", "strict", "lane", "bvh"])
 def test_triangle_soup_all_octants(mode):
     """3 000 overlapping triangles in 3 objects: rays from every octant, inside and outside the geometry."""
     sd = _soup_scene(3000, 31)
@@ -171,7 +171,7 @@ def test_exact_ties_resolve_like_the_reference_order():
     rays = np.concatenate([_primary_rays(sd, 160, 160), _random_rays(20000, 5, box=0.6)])
     want = o.trace_closest(rays)
     assert (want["prim"] >= 0).sum() > 5000 and (want["prim"][want["prim"] >= 0] < 400).all()   # first object wins every tie
-    for mode in ("fast", "strict", "lane"):
+    for mode in ("fast", "strict", "lane", "bvh"):
         g = host.Scene(sd); g.set_traversal(mode)
         _assert_hits_equal(g.trace_closest(rays), want)
         g.close()
