@@ -229,7 +229,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.shadow_bias = d->shadow_bias; v.refract_bias = d->refract_bias;
     s->eps_f = rt_float_above(0.000001);          // `epsilon`, hw4.cpp:18
     s->nprim = d->nprim;
-    if (const char* e = getenv("RT_TRAVERSAL")) s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "lane") == 0) ? 2 : (strcmp(e, "bvh") == 0) ? 3 : 1;
+    if (const char* e = getenv("RT_TRAVERSAL"))
+        s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "fast") == 0) ? 1 : (strcmp(e, "lane") == 0) ? 2 : (strcmp(e, "bvh") == 0) ? 3 : s->fast;
     if (const char* e = getenv("RT_FUSED_PRIMARY")) s->fused_primary = atoi(e) != 0;
     if (const char* e = getenv("RT_LANE_DEPTH")) s->lane_depth = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("RT_KNN")) s->knn_fast = (strcmp(e, "strict") == 0) ? 0 : 1;

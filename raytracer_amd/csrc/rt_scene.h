@@ -28,7 +28,8 @@ struct rt_scene {
     int knn_fast = 1;                 // radiance estimate: 1 = wave-shared kernel (default), 0 = strict list replay
     int fused_primary = 1;            // rt_render with primary_only: one kernel for the whole frame (RT_OPT_FUSED_PRIMARY)
     int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
-    int fast = 1;                     // traversal: 1 = ordered + culled, 2 = the same per lane, 0 = strict reference order
+    int fast = 3;                     // traversal: 3 = the build's own BVH (default), 1 = the reference's tree, ordered + culled
+                                      // (4.1b), 2 = the same per lane, 0 = strict reference order
     rt_scene_info info;
     std::vector<rt_light> host_lights;
     std::vector<void*> allocs;

@@ -218,7 +218,9 @@ __device__ __forceinline__ float lateral_slack(float gm, float area2_min, bool c
     if (cone) {
         const float c = __builtin_fabsf(r.dx * axis[0] + r.dy * axis[1] + r.dz * axis[2]) * aux.rlen;
         const float cc = __builtin_fminf(c, 1.0f);
-        const float lb = cc * cos_t - sqrt_rn(1.0f - cc * cc) * sin_t;      // cos(angle + cone) <= |dir . n| / |dir|
+        // cos(angle + cone) <= |dir . n| / |dir|; the hardware square root is good to 1 ulp of a value <= 1, which the
+        // 2e-7 covers
+        const float lb = (cc * cos_t - 2e-7f) - __builtin_amdgcn_sqrtf(1.0f - cc * cc) * sin_t;
         D = __builtin_fmaxf(D, area2_min * lb * aux.dlen * 0.999f);
     }
     return D > 1e-12f ? 1.2e-6f * dg * __builtin_amdgcn_rcpf(D) : 1e30f;      // 1.2e-6 leaves a third of room over 15 eps
@@ -550,7 +552,7 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
             if (nd.meta & 0x200) {                           // wave-uniform
                 const float c = __builtin_fabsf(r.dx * nd.axis[0] + r.dy * nd.axis[1] + r.dz * nd.axis[2]) * aux.rlen;
                 const float cc = __builtin_fminf(c, 1.0f);
-                const float lb = cc * nd.cos_t - sqrt_rn(1.0f - cc * cc) * nd.sin_t;     // cos(angle + cone) <= |dir . n| / |dir|
+                const float lb = (cc * nd.cos_t - 2e-7f) - __builtin_amdgcn_sqrtf(1.0f - cc * cc) * nd.sin_t;   // cos(angle + cone) <= |dir . n| / |dir|
                 if (lb > 0.0f) lat = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
             }
             const float sl = __builtin_fmaf(lat, reach, sl0);
