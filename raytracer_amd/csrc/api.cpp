@@ -204,6 +204,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!rc) rc = upload(s, flat.loose, &v.loose);
     for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.bvh_nodes[o], &v.bvh_oct[o]);
     v.nbvh = (int32_t)flat.bvh_nodes[0].size();
+    memcpy(v.bvh_root_centre, flat.bvh_root_centre, sizeof v.bvh_root_centre);
     if (!rc) rc = upload(s, flat.bvh_tris, &v.bvh_tris);
     if (!rc) rc = upload(s, flat.bvh_tri_ref, &v.bvh_tri_ref);
     if (!rc) rc = upload(s, flat.bvh_ref_leaf, &v.bvh_ref_leaf);

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -23,12 +24,18 @@ struct BNode {
     int axis = 0;
     std::unique_ptr<BNode> l, r;
     float lo[3], hi[3];
-    float gm = 0.f, amin = 0.f;
+    float gm = 0.f, amin = 0.f, emax = 0.f;   // max |e1||e2|, min |e1 x e2|, max of |e1|, |e2|
     float cone[3] = {0, 0, 1}, cos_t = 0.f, sin_t = 1.f;
     bool use_cone = false;
 };
 
-constexpr int64_t CONE_MAX = 256;      // subtrees up to this many triangles get a normal cone of their own
+static int64_t env_i64(const char* name, int64_t dflt) { const char* e = getenv(name); return e && *e ? atoll(e) : dflt; }
+static double env_f(const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; }
+// tuning knobs (measured defaults)
+static const int64_t CONE_MAX = env_i64("RT_BVH_CONE_MAX", 256);   // subtrees up to this many triangles get a normal cone of their own
+static const int64_t LEAF_MAX = std::min<int64_t>(env_i64("RT_BVH_LEAF", RT_GROUP), 255);
+static const double SIZE_THR = env_f("RT_BVH_SIZE_THR", 8.0);
+static const double CONE_COS = env_f("RT_BVH_CONE_COS", 0.2);
 
 struct BvhBuilder {
     const rt_scene_desc* d;
@@ -39,7 +46,7 @@ struct BvhBuilder {
     float centroid(int32_t p, int ax) const { const float* f = d->prims[p].f; return (f[ax] + f[3 + ax] + f[6 + ax]) * (1.0f / 3.0f); }
 
     void leaf_stats(BNode& n) const {
-        float gm = 0.f; double amin = 1e300, ax[3] = {0, 0, 0};
+        float gm = 0.f, emax = 0.f; double amin = 1e300, ax[3] = {0, 0, 0};
         std::vector<std::array<double, 3>> nrm;
         const bool want_cone = n.b - n.a <= CONE_MAX;
         for (int k = 0; k < 3; ++k) { n.lo[k] = 1e30f; n.hi[k] = -1e30f; }
@@ -51,7 +58,7 @@ struct BvhBuilder {
                 for (int v = 0; v < 3; ++v) { n.lo[k] = std::min(n.lo[k], f[3 * v + k]); n.hi[k] = std::max(n.hi[k], f[3 * v + k]); }
             }
             const float l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
-            gm = std::max(gm, l1 * l2);
+            gm = std::max(gm, l1 * l2); emax = std::max(emax, std::max(l1, l2));
             const double cx = (double)e1[1] * e2[2] - (double)e1[2] * e2[1], cy = (double)e1[2] * e2[0] - (double)e1[0] * e2[2],
                          cz = (double)e1[0] * e2[1] - (double)e1[1] * e2[0];
             const double ar = std::sqrt(cx * cx + cy * cy + cz * cz);
@@ -64,7 +71,7 @@ struct BvhBuilder {
                 }
             } else amin = 0.0;
         }
-        n.gm = gm;
+        n.gm = gm; n.emax = emax;
         n.amin = amin >= 1e299 ? 0.f : (float)(amin * (1.0 - 1e-5));
         n.use_cone = false;
         if (want_cone && !nrm.empty() && amin > 0) {
@@ -73,7 +80,7 @@ struct BvhBuilder {
                 double cmin = 1.0;
                 for (const auto& u : nrm) cmin = std::min(cmin, (u[0] * ax[0] + u[1] * ax[1] + u[2] * ax[2]) / al);
                 cmin = std::max(-1.0, cmin - 1e-4);                  // round the cone outwards
-                if (cmin > 0.2) {                                     // wider cones bound nothing useful
+                if (cmin > CONE_COS) {                                     // wider cones bound nothing useful
                     for (int k = 0; k < 3; ++k) n.cone[k] = (float)(ax[k] / al);
                     n.cos_t = (float)cmin; n.sin_t = (float)std::min(1.0, std::sqrt(std::max(0.0, 1.0 - cmin * cmin)) + 1e-4);
                     n.use_cone = true;
@@ -141,7 +148,7 @@ struct BvhBuilder {
 
     void build(BNode& n, int depth = 0) {
         const int64_t cnt = n.b - n.a;
-        if (cnt <= RT_GROUP) { leaf_stats(n); return; }
+        if (cnt <= LEAF_MAX) { leaf_stats(n); return; }
         // A node's box is inflated in proportion to the LARGEST |e1| |e2| below it (trace_device.h: lateral_slack): a
         // few big triangles among small ones (a floor under a mesh) would loosen every box above them.  They are
         // split off by size first: triangles above 8 x the median product go to a child of their own.
@@ -150,7 +157,7 @@ struct BvhBuilder {
             std::vector<float> g((size_t)cnt);
             for (int64_t j = 0; j < cnt; ++j) g[(size_t)j] = gm_of[(size_t)idx[(size_t)(n.a + j)]];
             std::nth_element(g.begin(), g.begin() + cnt / 2, g.end());
-            const float thr = 8.0f * g[(size_t)(cnt / 2)];
+            const float thr = (float)SIZE_THR * g[(size_t)(cnt / 2)];
             auto small_first = [this, thr](int32_t p) { return !(gm_of[(size_t)p] > thr); };
             const int64_t nsmall = std::count_if(idx.begin() + n.a, idx.begin() + n.b, small_first);
             if (nsmall < cnt && cnt - nsmall <= cnt / 4) {
@@ -182,7 +189,7 @@ struct BvhBuilder {
             other.join();
         } else { build(*n.l, depth + 1); build(*n.r, depth + 1); }
         for (int k = 0; k < 3; ++k) { n.lo[k] = std::min(n.l->lo[k], n.r->lo[k]); n.hi[k] = std::max(n.l->hi[k], n.r->hi[k]); }
-        n.gm = std::max(n.l->gm, n.r->gm);
+        n.gm = std::max(n.l->gm, n.r->gm); n.emax = std::max(n.l->emax, n.r->emax);
         n.amin = std::min(n.l->amin, n.r->amin);
         if (cnt <= CONE_MAX) {                                        // a cone of its own where it can be narrow
             BNode tmp; tmp.a = n.a; tmp.b = n.b;
@@ -191,26 +198,32 @@ struct BvhBuilder {
         }
     }
 
-    void emit(const BNode& n, int depth, int o, std::vector<DevBvhNode>& out) const {
+    void emit(const BNode& n, int depth, int o, const double* croot, std::vector<DevBvhNode>& out) const {
         const size_t me = out.size();
         out.emplace_back();
         const bool leaf = !n.l;
         if (!leaf) {
             const bool right_first = (o >> n.axis) & 1;
-            emit(right_first ? *n.r : *n.l, depth + 1, o, out);
-            emit(right_first ? *n.l : *n.r, depth + 1, o, out);
+            emit(right_first ? *n.r : *n.l, depth + 1, o, croot, out);
+            emit(right_first ? *n.l : *n.r, depth + 1, o, croot, out);
         }
         DevBvhNode& r = out[me];
         memcpy(r.lo, n.lo, 12); memcpy(r.hi, n.hi, 12);
-        {   // lateral_slack (trace_device.h) for |dir| in [0.999, 1.001], the rays traverse_bvh takes
+        {   // lateral_slack (trace_device.h) for |dir| in [0.999, 1.001], the rays traverse_bvh takes; 15 eps = 8.9e-7 is
+            // applied as 1.0e-6
             const double g = 1.001 * (double)n.gm, d0 = 1e-6 - 4.0e-7 * g;
-            r.slack = d0 > 1e-12 ? (float)std::min(1e30, (1.2e-6 * g / d0) * (1.0 + 1e-6) + 2e-5) : 1e30f;
-            r.cone_k = n.amin > 0.f ? (float)std::min(1e30, (1.2e-6 * g / (0.999 * (double)n.amin)) * (1.0 + 1e-6)) : 1e30f;
+            r.slack = d0 > 1e-12 ? (float)std::min(1e30, (1.0e-6 * g / d0) * (1.0 + 1e-6) + 2e-5) : 1e30f;
+            r.cone_k = n.amin > 0.f ? (float)std::min(1e30, (1.0e-6 * g / (0.999 * (double)n.amin)) * (1.0 + 1e-6)) : 1e30f;
+            double dc = 0.0, rad = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double c = 0.5 * ((double)n.lo[k] + n.hi[k]) - croot[k], h = 0.5 * ((double)n.hi[k] - n.lo[k]);
+                dc += c * c; rad += h * h;
+            }
+            r.rho = (float)((std::sqrt(dc) + std::sqrt(rad) + 0.88 * (double)n.emax) * (1.0 + 1e-5) + 1e-30);
         }
         memcpy(r.axis, n.cone, 12); r.cos_t = n.cos_t; r.sin_t = n.sin_t;
-        r.skip = (int32_t)out.size();
+        r.skip = leaf ? (int32_t)n.a : (int32_t)out.size();
         r.meta = (depth & 0xff) | (leaf ? 0x100 : 0) | (n.use_cone ? 0x200 : 0) | (leaf ? (int32_t)(n.b - n.a) << 16 : 0);
-        r.first = leaf ? (int32_t)n.a : 0;
     }
 };
 
@@ -297,13 +310,16 @@ int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err) 
         flat->bvh_tris[(size_t)j] = t;
         flat->bvh_tri_ref[(size_t)j * 2] = first_of[(size_t)p]; flat->bvh_tri_ref[(size_t)j * 2 + 1] = count_of[(size_t)p];
     }
+    double croot[3];
+    for (int k = 0; k < 3; ++k) croot[k] = 0.5 * ((double)root.lo[k] + root.hi[k]);
     if (nth > 1 && nt > 4096) {
         std::vector<std::thread> th;
-        for (int o = 0; o < 8; ++o) th.emplace_back([&B, &root, flat, o] { B.emit(root, 0, o, flat->bvh_nodes[o]); });
+        for (int o = 0; o < 8; ++o) th.emplace_back([&B, &root, flat, o, &croot] { B.emit(root, 0, o, croot, flat->bvh_nodes[o]); });
         for (std::thread& t : th) t.join();
     } else {
-        for (int o = 0; o < 8; ++o) B.emit(root, 0, o, flat->bvh_nodes[o]);
+        for (int o = 0; o < 8; ++o) B.emit(root, 0, o, croot, flat->bvh_nodes[o]);
     }
+    for (int k = 0; k < 3; ++k) flat->bvh_root_centre[k] = (float)croot[k];
     if (flat->bvh_nodes[0].size() > (size_t)INT32_MAX / 2) { *err = "BVH exceeds 2^30 nodes"; return RT_E_LIMIT; }
     return RT_OK;
 }

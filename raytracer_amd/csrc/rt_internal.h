@@ -67,9 +67,9 @@ struct DevBvhNode {         // 64 B
     float cone_k;           // with the cone: the inflation per unit reach is cone_k / cos(angle + cone), if smaller
     float axis[3];          // normal cone: axis, cos, sin of the half angle (rounded outwards); valid if meta & 0x200
     float cos_t, sin_t;
-    int32_t skip;           // next node when the subtree is not entered
+    int32_t skip;           // inner node: next node when the subtree is not entered; leaf (next = index + 1): first record in bvh_tris
     int32_t meta;           // depth | leaf << 8 | cone << 9 | (leaf: triangle count) << 16
-    int32_t first;          // leaf: first record in bvh_tris
+    float rho;              // |orig - root centre| + rho >= |orig - v0| + 0.44 (|e1| + |e2|) for every triangle below
 };
 static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode must be 64 bytes");
 struct DevRefLeaf { int32_t leaf; int32_t rank; };   // a reference leaf (index in layout 7) holding a triangle, and the
@@ -118,6 +118,7 @@ struct DevSceneView {       // passed by value to kernels
     const DevLoose* loose; int32_t nloose;
     // the build's own hierarchy; nbvh = 0: none
     const DevBvhNode* bvh_oct[8]; int32_t nbvh;
+    float bvh_root_centre[3];           // what DevBvhNode::rho is measured from (the root box's centre, rounded)
     const DevLeafTri* bvh_tris;         // every tree triangle once; .rank = its index t into bvh_tri_ref
     const int32_t* bvh_tri_ref;         // [t][2]: first, count into bvh_ref_leaf
     const DevRefLeaf* bvh_ref_leaf;     // the reference leaves holding triangle t, by rising rank
@@ -151,6 +152,7 @@ struct HostFlatScene {
     std::vector<DevRefLeaf> bvh_ref_leaf;
     std::vector<int32_t> ref_parent;
     std::vector<float> ref_chain_box;
+    float bvh_root_centre[3] = {0.f, 0.f, 0.f};
     std::vector<float> prim_normal;
     std::vector<float> prim_geom;
     int64_t kd_nodes_built = 0;

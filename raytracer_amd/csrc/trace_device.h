@@ -527,17 +527,17 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
     const DevBvhNode* __restrict__ nodes = sc.bvh_oct[oct];
     const float far_limit = ANY ? (use_tmax ? tmax : 1e9f) : 0.f;
     const int nn = sc.nbvh;
-    float reach = 0.f;
-    {   // |orig - v0| + 0.44 (|e1| + |e2|) for every triangle: origin to the root box's centre + 3 x its half diagonal
-        const DevBvhNode rt = nodes[0];
-        const float cx = 0.5f * (rt.lo[0] + rt.hi[0]) - r.ox, cy = 0.5f * (rt.lo[1] + rt.hi[1]) - r.oy, cz = 0.5f * (rt.lo[2] + rt.hi[2]) - r.oz;
-        const float hx = rt.hi[0] - rt.lo[0], hy = rt.hi[1] - rt.lo[1], hz = rt.hi[2] - rt.lo[2];
-        reach = 1.001f * (sqrt_rn(cx * cx + cy * cy + cz * cz) + 1.5f * sqrt_rn(hx * hx + hy * hy + hz * hz)) + 1e-6f;
+    const float oabs = __builtin_fabsf(r.ox) + __builtin_fabsf(r.oy) + __builtin_fabsf(r.oz);
+    // reach of a node = d0 + its rho >= |orig - v0| + 0.44 (|e1| + |e2|) for every triangle below it (lateral_slack)
+    float d0;
+    {
+        const float cx = sc.bvh_root_centre[0] - r.ox, cy = sc.bvh_root_centre[1] - r.oy, cz = sc.bvh_root_centre[2] - r.oz;
+        d0 = 1.001f * sqrt_rn(cx * cx + cy * cy + cz * cz) + 1e-6f * oabs + 1e-6f;
     }
     // slabs as one fused multiply-add per plane, (bound -+ sl) * (1/d) - orig * (1/d): against the subtraction first, the
     // plane moves by <= 3 eps (|orig| + |bound|), which the constant part of the inflation covers
     const float px = -(r.ox * aux.rx), py = -(r.oy * aux.ry), pz = -(r.oz * aux.rz);
-    const float sl0 = 1e-6f + 1e-6f * (__builtin_fabsf(r.ox) + __builtin_fabsf(r.oy) + __builtin_fabsf(r.oz)) + 1e-6f * reach;
+    const float sl0 = 1e-6f + 2e-6f * oabs + 1e-6f * (d0 + nodes[0].rho);
     int i = 0;
     while (i < nn) {
         if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
@@ -555,7 +555,7 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
                 const float lb = (cc * nd.cos_t - 2e-7f) - __builtin_amdgcn_sqrtf(1.0f - cc * cc) * nd.sin_t;   // cos(angle + cone) <= |dir . n| / |dir|
                 if (lb > 0.0f) lat = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
             }
-            const float sl = __builtin_fmaf(lat, reach, sl0);
+            const float sl = __builtin_fmaf(lat, d0 + nd.rho, sl0);
             const float x0 = __builtin_fmaf(nd.lo[0] - sl, aux.rx, px), x1 = __builtin_fmaf(nd.hi[0] + sl, aux.rx, px);
             const float y0 = __builtin_fmaf(nd.lo[1] - sl, aux.ry, py), y1 = __builtin_fmaf(nd.hi[1] + sl, aux.ry, py);
             const float z0 = __builtin_fmaf(nd.lo[2] - sl, aux.rz, pz), z1 = __builtin_fmaf(nd.hi[2] + sl, aux.rz, pz);
@@ -565,9 +565,10 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
             hit = !(ex < en || ex * aux.dlen < 0.0f || en * aux.dlen > limit);
             if (!hit) fail = depth;
         }
-        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
-        if (nd.meta & 0x100) {
-            const int t0 = nd.first, t1 = nd.first + (nd.meta >> 16);
+        const bool leaf = (nd.meta & 0x100) != 0;
+        if (__ballot(hit) == 0ull) { i = leaf ? i + 1 : nd.skip; continue; }
+        if (leaf) {
+            const int t0 = nd.skip, t1 = nd.skip + (nd.meta >> 16);
             for (int ti = t0; ti < t1; ++ti) {
                 const DevLeafTri* __restrict__ t = sc.bvh_tris + ti;                // wave-uniform
                 if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
