@@ -205,6 +205,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.bvh_nodes[o], &v.bvh_oct[o]);
     v.nbvh = (int32_t)flat.bvh_nodes[0].size();
     memcpy(v.bvh_root_centre, flat.bvh_root_centre, sizeof v.bvh_root_centre);
+    v.bvh_root_rho = v.nbvh > 0 ? flat.bvh_nodes[0][0].rho : 0.f;
+    if (!rc) {
+        void* q = nullptr;
+        if (hipMalloc(&q, 64) != hipSuccess) rc = rt_fail(RT_E_NOMEM, "hipMalloc failed");
+        else { s->allocs.push_back(q); v.ray_counter = (uint32_t*)q; }
+    }
     if (!rc) rc = upload(s, flat.bvh_tris, &v.bvh_tris);
     if (!rc) rc = upload(s, flat.bvh_tri_ref, &v.bvh_tri_ref);
     if (!rc) rc = upload(s, flat.bvh_ref_leaf, &v.bvh_ref_leaf);

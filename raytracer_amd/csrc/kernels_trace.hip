@@ -20,6 +20,7 @@
 // operations in the reference's order on the nodes the reference would visit.
 //
 // Compile with -ffp-contract=off and correctly rounded f32 divide / sqrt.
+#include <cstdlib>
 #include "trace_device.h"
 #include "rng_device.h"
 
@@ -66,12 +67,13 @@ k_trace_any(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __r
 // its slot at once
 extern "C" __global__ void __launch_bounds__(64)
 k_trace_closest_lane(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                     int64_t n, float eps_f, rt_hit* __restrict__ out) {
+                     int64_t n, float eps_f, int unfit_only, rt_hit* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inb = i < n;
-    const bool valid = inb && (active == nullptr || active[i] >= 0);
+    bool inb = i < n;
+    bool valid = inb && (active == nullptr || active[i] >= 0);
     Rayf r = {0, 0, 0, 0, 0, 1};
     if (valid) r = load_ray(rays, i);
+    if (unfit_only) { valid = valid && !bvh_fit(ray_aux(r)); inb = valid; }    // the rest was k_trace_closest_bvh_lanes' 
     Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
     bool occ = false;
     traverse_lane<false>(sc, r, valid, eps_f, 0.f, false, best, occ);
@@ -85,18 +87,90 @@ k_trace_closest_lane(DevSceneView sc, const rt_ray* __restrict__ rays, const int
 
 extern "C" __global__ void __launch_bounds__(64)
 k_trace_any_lane(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                 const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
+                 const float* __restrict__ tmax, int64_t n, float eps_f, int unfit_only, uint8_t* __restrict__ occluded) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inb = i < n;
-    const bool valid = inb && (active == nullptr || active[i] >= 0);
+    bool inb = i < n;
+    bool valid = inb && (active == nullptr || active[i] >= 0);
     Rayf r = {0, 0, 0, 0, 0, 1};
     float tm = 0.f;
     if (valid) { r = load_ray(rays, i); if (tmax) tm = tmax[i]; }
+    if (unfit_only) { valid = valid && !bvh_fit(ray_aux(r)); inb = valid; }    // the rest was k_trace_any_bvh_lanes' 
     Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
     bool occ = false;
     traverse_lane<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
     loose_prims<true>(sc, r, valid, eps_f, tm, tmax != nullptr, best, occ);
     if (inb) occluded[i] = occ ? 1 : 0;
+}
+
+// Per-lane walk of the build's own hierarchy with lanes refilled from the launch's rays (trace_device.h: BvhLaneWalk):
+// a fixed number of waves; a lane whose ray is finished writes its result and takes the next unclaimed ray.  Rays that
+// traverse_bvh does not take (zero / non-finite components, not unit length) are left for k_trace_*_lane; inactive
+// rays get the "no hit" result here.  Needs nbvh > 0 and nloose == 0 (the launchers check).
+template <bool ANY>
+__device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                                          const float* __restrict__ tmax, int64_t n, float eps_f,
+                                          rt_hit* __restrict__ out, uint8_t* __restrict__ occluded) {
+    const int lane = threadIdx.x & 63;
+    const bool use_tmax = tmax != nullptr;
+    bool have = false, more = true, occ = false;
+    int64_t idx = 0;
+    BvhLaneWalk wk; wk.i = 0; wk.far_limit = 0.f; wk.nodes = sc.bvh_oct[0];
+    wk.r = Rayf{0, 0, 0, 0, 0, 1};
+    wk.bc = BvhConsts{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+    for (;;) {
+        const unsigned long long need = __ballot(!have && more);
+        if (need != 0ull) {
+            const int first = __builtin_ctzll(need);
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(sc.ray_counter, (uint32_t)__builtin_popcountll(need));
+            base = __shfl(base, first, 64);
+            if (!have && more) {
+                const int64_t my = (int64_t)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
+                if (my >= n) more = false;
+                else if (active != nullptr && active[my] < 0) {
+                    if (ANY) occluded[my] = 0;
+                    else {
+                        float* o = reinterpret_cast<float*>(out + my);
+                        reinterpret_cast<int32_t*>(o)[0] = -1; o[1] = 1e9f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f;
+                    }
+                } else {
+                    const Rayf r = load_ray(rays, my);
+                    const RayAux aux = ray_aux(r);
+                    if (bvh_fit(aux)) {
+                        idx = my; have = true; occ = false;
+                        best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+                        bvh_lane_start(sc, r, aux, ANY ? (use_tmax ? tmax[my] : 1e9f) : 0.f, wk);
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) { if (__ballot(more) == 0ull) break; continue; }
+        int t0, t1;
+        bvh_lane_next_leaf<ANY>(sc, wk, have, best, t0, t1);
+        if (have && t0 < t1) { if (bvh_lane_leaf<ANY>(sc, wk, t0, t1, eps_f, use_tmax, best)) occ = true; }
+        if (have && wk.i >= sc.nbvh) {
+            if (ANY) occluded[idx] = occ ? 1 : 0;
+            else {
+                float* o = reinterpret_cast<float*>(out + idx);
+                reinterpret_cast<int32_t*>(o)[0] = best.prim;
+                o[1] = best.len; o[2] = best.px; o[3] = best.py; o[4] = best.pz;
+            }
+            have = false;
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_trace_closest_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                          int64_t n, float eps_f, rt_hit* __restrict__ out) {
+    bvh_lanes<false>(sc, rays, active, nullptr, n, eps_f, out, nullptr);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_trace_any_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                      const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
+    bvh_lanes<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded);
 }
 
 // the build's own hierarchy instead of the reference's tree (trace_device.h: traverse_bvh)
@@ -250,6 +324,17 @@ k_generate_drt(rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntiles,
 // ---------------------------------------------------------------------------
 // host launchers (declared in rt_internal.h)
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+// the refilling per-lane BVH kernels: RT_LANE_BVH=0 keeps the reference-tree walk for every ray
+static inline int bvh_lanes_usable(const DevSceneView& sc) {
+    static const int on = [] { const char* e = getenv("RT_LANE_BVH"); return e ? atoi(e) : 1; }();
+    return (on && sc.nbvh > 0 && sc.nloose == 0 && sc.ray_counter != nullptr) ? 1 : 0;
+}
+// waves of a refilling kernel: enough to fill the chip several times over, never more than the rays need
+static inline unsigned lanes_grid(int64_t n) {
+    static const int64_t cap = [] { const char* e = getenv("RT_LANE_WAVES"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)8192; }();
+    const int64_t w = (n + 63) / 64;
+    return (unsigned)(w < cap ? w : cap);
+}
 
 hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
                              float eps_f, int fast, rt_hit* d_out, hipStream_t st) {
@@ -259,7 +344,13 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
         return hipGetLastError();
     }
     if (fast == 2) {
-        hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
+        const int lanes = bvh_lanes_usable(sc);
+        if (lanes) {
+            hipError_t e = hipMemsetAsync(sc.ray_counter, 0, sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
+        }
+        hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, lanes, d_out);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, fast, d_out);
@@ -274,7 +365,13 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
         return hipGetLastError();
     }
     if (fast == 2) {
-        hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+        const int lanes = bvh_lanes_usable(sc);
+        if (lanes) {
+            hipError_t e = hipMemsetAsync(sc.ray_counter, 0, sizeof(uint32_t), st);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+        }
+        hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, lanes, d_occ);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_trace_any, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, fast, d_occ);

@@ -512,13 +512,51 @@ __device__ __forceinline__ int reachable_rank(const DevSceneView& sc, int tref, 
     return 0x7fffffff;
 }
 
+// per-ray constants of the BVH walk
+struct BvhConsts {
+    float rx, ry, rz, dlen, rlen;
+    float px, py, pz;      // -orig * (1/d) per axis
+    float d0;              // reach of a node = d0 + its rho >= |orig - v0| + 0.44 (|e1| + |e2|) for every triangle below it
+    float sl0;             // the constant part of the inflation
+};
+__device__ __forceinline__ BvhConsts bvh_consts(const DevSceneView& sc, const Rayf& r, const RayAux& aux, float root_rho) {
+    BvhConsts b;
+    b.rx = aux.rx; b.ry = aux.ry; b.rz = aux.rz; b.dlen = aux.dlen; b.rlen = aux.rlen;
+    const float oabs = __builtin_fabsf(r.ox) + __builtin_fabsf(r.oy) + __builtin_fabsf(r.oz);
+    const float cx = sc.bvh_root_centre[0] - r.ox, cy = sc.bvh_root_centre[1] - r.oy, cz = sc.bvh_root_centre[2] - r.oz;
+    b.d0 = 1.001f * sqrt_rn(cx * cx + cy * cy + cz * cz) + 1e-6f * oabs + 1e-6f;
+    // slabs as one fused multiply-add per plane, (bound -+ sl) * (1/d) - orig * (1/d): against the subtraction first, the
+    // plane moves by <= 3 eps (|orig| + |bound|), which the constant part of the inflation covers
+    b.px = -(r.ox * aux.rx); b.py = -(r.oy * aux.ry); b.pz = -(r.oz * aux.rz);
+    b.sl0 = 1e-6f + 2e-6f * oabs + 1e-6f * (b.d0 + root_rho);
+    return b;
+}
+// does the ray pass the node's box, inflated by the slack of the triangles below it, in front of the origin and not
+// beyond `limit`?
+__device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r, const BvhConsts& b, float limit) {
+    float lat = nd.slack;
+    if (nd.meta & 0x200) {
+        const float c = __builtin_fabsf(r.dx * nd.axis[0] + r.dy * nd.axis[1] + r.dz * nd.axis[2]) * b.rlen;
+        const float cc = __builtin_fminf(c, 1.0f);
+        const float lb = (cc * nd.cos_t - 2e-7f) - __builtin_amdgcn_sqrtf(1.0f - cc * cc) * nd.sin_t;   // cos(angle + cone) <= |dir . n| / |dir|
+        if (lb > 0.0f) lat = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
+    }
+    const float sl = __builtin_fmaf(lat, b.d0 + nd.rho, b.sl0);
+    const float x0 = __builtin_fmaf(nd.lo[0] - sl, b.rx, b.px), x1 = __builtin_fmaf(nd.hi[0] + sl, b.rx, b.px);
+    const float y0 = __builtin_fmaf(nd.lo[1] - sl, b.ry, b.py), y1 = __builtin_fmaf(nd.hi[1] + sl, b.ry, b.py);
+    const float z0 = __builtin_fmaf(nd.lo[2] - sl, b.rz, b.pz), z1 = __builtin_fmaf(nd.hi[2] + sl, b.rz, b.pz);
+    const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+    return !(ex < en || ex * b.dlen < 0.0f || en * b.dlen > limit);
+}
+__device__ __forceinline__ bool bvh_fit(const RayAux& aux) { return aux.plain && aux.dlen > 0.999f && aux.dlen < 1.001f; }
+
 template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf& r, bool valid,
                                              float eps_f, float tmax, bool use_tmax,
                                              Closest& best, bool& occluded, Work* w = nullptr) {
     const RayAux aux = ray_aux(r);
-    const bool fit = aux.plain && aux.dlen > 0.999f && aux.dlen < 1.001f;
-    if (__ballot(valid && !fit) != 0ull || sc.nbvh == 0) { traverse_fast<ANY, COUNT>(sc, r, valid, eps_f, tmax, use_tmax, best, occluded, w); return; }
+    if (__ballot(valid && !bvh_fit(aux)) != 0ull || sc.nbvh == 0) { traverse_fast<ANY, COUNT>(sc, r, valid, eps_f, tmax, use_tmax, best, occluded, w); return; }
     int fail = valid ? RT_ALIVE : RT_DEAD;
     const unsigned long long vm = __ballot(valid);
     if (vm == 0ull) return;
@@ -527,17 +565,7 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
     const DevBvhNode* __restrict__ nodes = sc.bvh_oct[oct];
     const float far_limit = ANY ? (use_tmax ? tmax : 1e9f) : 0.f;
     const int nn = sc.nbvh;
-    const float oabs = __builtin_fabsf(r.ox) + __builtin_fabsf(r.oy) + __builtin_fabsf(r.oz);
-    // reach of a node = d0 + its rho >= |orig - v0| + 0.44 (|e1| + |e2|) for every triangle below it (lateral_slack)
-    float d0;
-    {
-        const float cx = sc.bvh_root_centre[0] - r.ox, cy = sc.bvh_root_centre[1] - r.oy, cz = sc.bvh_root_centre[2] - r.oz;
-        d0 = 1.001f * sqrt_rn(cx * cx + cy * cy + cz * cz) + 1e-6f * oabs + 1e-6f;
-    }
-    // slabs as one fused multiply-add per plane, (bound -+ sl) * (1/d) - orig * (1/d): against the subtraction first, the
-    // plane moves by <= 3 eps (|orig| + |bound|), which the constant part of the inflation covers
-    const float px = -(r.ox * aux.rx), py = -(r.oy * aux.ry), pz = -(r.oz * aux.rz);
-    const float sl0 = 1e-6f + 2e-6f * oabs + 1e-6f * (d0 + nodes[0].rho);
+    const BvhConsts bc = bvh_consts(sc, r, aux, sc.bvh_root_rho);
     int i = 0;
     while (i < nn) {
         if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
@@ -548,21 +576,7 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
         if (COUNT) w->fetch += 1;
         if (fail == RT_ALIVE) {
             if (COUNT) w->box += 1;
-            float lat = nd.slack;
-            if (nd.meta & 0x200) {                           // wave-uniform
-                const float c = __builtin_fabsf(r.dx * nd.axis[0] + r.dy * nd.axis[1] + r.dz * nd.axis[2]) * aux.rlen;
-                const float cc = __builtin_fminf(c, 1.0f);
-                const float lb = (cc * nd.cos_t - 2e-7f) - __builtin_amdgcn_sqrtf(1.0f - cc * cc) * nd.sin_t;   // cos(angle + cone) <= |dir . n| / |dir|
-                if (lb > 0.0f) lat = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
-            }
-            const float sl = __builtin_fmaf(lat, d0 + nd.rho, sl0);
-            const float x0 = __builtin_fmaf(nd.lo[0] - sl, aux.rx, px), x1 = __builtin_fmaf(nd.hi[0] + sl, aux.rx, px);
-            const float y0 = __builtin_fmaf(nd.lo[1] - sl, aux.ry, py), y1 = __builtin_fmaf(nd.hi[1] + sl, aux.ry, py);
-            const float z0 = __builtin_fmaf(nd.lo[2] - sl, aux.rz, pz), z1 = __builtin_fmaf(nd.hi[2] + sl, aux.rz, pz);
-            const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-            const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-            const float limit = ANY ? far_limit : best.len;
-            hit = !(ex < en || ex * aux.dlen < 0.0f || en * aux.dlen > limit);
+            hit = bvh_box_hit(nd, r, bc, ANY ? far_limit : best.len);
             if (!hit) fail = depth;
         }
         const bool leaf = (nd.meta & 0x100) != 0;
@@ -625,6 +639,89 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
         }
         i = i + 1;
     }
+}
+
+// ---------------------------------------------------------------------------
+// BVH walk PER LANE, for rays that are not coherent across a wave: the state of one ray's walk, advanced in
+// the "while-while" shape of traverse_lane -- to the next leaf whose box the ray passes, then through its triangles.
+// The kernels (k_trace_*_bvh_lanes) keep a wave's 64 lanes busy by handing a lane the next ray of the launch as soon as
+// its own is finished, so a launch costs the SUM of the rays' walks, not the sum over waves of the longest walk.
+// Same tests and the same accept rule as traverse_bvh.
+struct BvhLaneWalk {
+    Rayf r; BvhConsts bc; const DevBvhNode* nodes;
+    int i;                 // node cursor; >= nbvh: the walk is over
+    float far_limit;       // any-hit: the distance to stay under
+};
+__device__ __forceinline__ void bvh_lane_start(const DevSceneView& sc, const Rayf& r, const RayAux& aux, float far_limit, BvhLaneWalk& wk) {
+    const int oct = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
+    const DevBvhNode* nodes = sc.bvh_oct[0];
+#pragma unroll
+    for (int o = 1; o < 8; ++o) if (oct == o) nodes = sc.bvh_oct[o];
+    wk.r = r; wk.nodes = nodes; wk.i = 0; wk.far_limit = far_limit;
+    wk.bc = bvh_consts(sc, r, aux, sc.bvh_root_rho);
+}
+// advances the lane (if `on`) to its next leaf; returns its triangle range
+template <bool ANY>
+__device__ __forceinline__ void bvh_lane_next_leaf(const DevSceneView& sc, BvhLaneWalk& wk, bool on, const Closest& best, int& t0, int& t1) {
+    t0 = t1 = 0;
+    const int nn = sc.nbvh;
+    while (on && t0 == t1 && wk.i < nn) {
+        const DevBvhNode nd = wk.nodes[wk.i];
+        const bool leaf = (nd.meta & 0x100) != 0;
+        const bool hit = bvh_box_hit(nd, wk.r, wk.bc, ANY ? wk.far_limit : best.len);
+        if (!hit) wk.i = leaf ? wk.i + 1 : nd.skip;
+        else {
+            wk.i = wk.i + 1;
+            if (leaf) { t0 = nd.skip; t1 = nd.skip + (nd.meta >> 16); }
+        }
+    }
+}
+// the triangles [t0, t1) of the lane's leaf; any-hit: returns true (and ends the walk) when one occludes
+template <bool ANY>
+__device__ __forceinline__ bool bvh_lane_leaf(const DevSceneView& sc, BvhLaneWalk& wk, int t0, int t1, float eps_f, bool use_tmax, Closest& best) {
+    const Rayf& r = wk.r;
+    for (int ti = t0; ti < t1; ++ti) {
+        const DevLeafTri* __restrict__ t = sc.bvh_tris + ti;
+        if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+        const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
+        const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
+        const float pvx = r.dy * e2z - r.dz * e2y;
+        const float pvy = r.dz * e2x - r.dx * e2z;
+        const float pvz = r.dx * e2y - r.dy * e2x;
+        const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+        if (__builtin_fabsf(det) < eps_f) continue;
+        const float ri = __builtin_amdgcn_rcpf(det);
+        const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
+        const float du = tx * pvx + ty * pvy + tz * pvz;
+        const float ua = du * ri;
+        if ((ua < -1e-30f) || (ua > 1.00001f)) continue;
+        const float qx = ty * e1z - tz * e1y;
+        const float qy = tz * e1x - tx * e1z;
+        const float qz = tx * e1y - ty * e1x;
+        const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
+        const float dt = e2x * qx + e2y * qy + e2z * qz;
+        const float va = dv * ri, ta = dt * ri;
+        if ((va < -1e-30f) || (ua + va > 1.00002f) || (ta < -1e-30f)) continue;
+        const float detInv = 1.0f / det;                                     // hw4.cpp:211-230, exactly
+        const float u = du * detInv;
+        if (u < 0 || u > 1.0f) continue;
+        const float v = dv * detInv;
+        if (v < 0 || u + v > 1.0f) continue;
+        const float tt = dt * detInv;
+        if (tt < 0) continue;
+        const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
+        const float len = dist_to(r, px, py, pz);
+        if (ANY) {
+            if (len < wk.far_limit && len >= sc.tol_f && reachable_rank(sc, t->rank, r) != 0x7fffffff) { wk.i = sc.nbvh; return true; }
+        } else if (len <= best.len && len >= sc.tol_f && (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
+            const int rr = reachable_rank(sc, t->rank, r);
+            if (rr != 0x7fffffff && (len < best.len || rr < best.rank)) {
+                best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                best.rank = rr;
+            }
+        }
+    }
+    return false;
 }
 
 // primitives outside every tree, in index order (the whole scene for final.cpp)

@@ -25,8 +25,8 @@ if len(sys.argv) > 1:
     print(sys.argv[1], {n: frame_ms(sd) for n, sd in scenes}, flush=True)
 else:
     import subprocess
-    settings = [{}] + [{"RT_BVH_LEAF": v} for v in (4, 8)] + [{"RT_BVH_CONE_MAX": v} for v in (48, 4096, 1 << 30)] + \
-               [{"RT_BVH_SIZE_THR": v} for v in (3, 1e9)] + [{"RT_BVH_CONE_COS": v} for v in (0.0, 0.5)]
+    settings = [{}] + [{"RT_BVH_LEAF": v} for v in (3, 4, 8)] + [{"RT_BVH_CONE_MAX": v} for v in (48, 4096)] + \
+               [{"RT_BVH_SIZE_THR": v} for v in (4, 16, 1e9)] + [{"RT_BVH_CONE_COS": v} for v in (0.0, 0.5, 0.7)]
     for s in settings:
         env = dict(os.environ, **{k: str(v) for k, v in s.items()})
         subprocess.run([sys.executable, __file__, str(s)], env=env, check=True, timeout=200)
