@@ -417,8 +417,12 @@ def main():
         if dry:
             frame.view(-1, 3)[my_pix] = torch.tensor([rank + 1, i & 255, 7], dtype=torch.uint8)
         else:
-            abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(), None, C.byref(st), sp))
-            if timed:
+            # timed steps ask for no rt_stats: the frames queue on the stream back to back (rt_stats needs a device -> host
+            # copy and a synchronisation per frame).  Every step renders the same frame, so its ray counts are those of the
+            # instrumented frames that follow the timed region.
+            abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(), None,
+                                         C.byref(st) if timed == "stats" else None, sp))
+            if timed == "stats":
                 tot["rays"] += st.rays_primary + st.rays_shadow
                 tot["closest_ms"] += st.trace_closest_ms; tot["any_ms"] += st.trace_any_ms
                 tot["closest_launches"] += st.trace_closest_launches; tot["closest_rays"] += st.rays_primary
@@ -462,6 +466,16 @@ def main():
         drain()
     sync()
     dt = time.perf_counter() - t0
+    # the same frame again with rt_stats, for the ray counts and the per-kernel HIP-event times of the roofline
+    nstat = 0
+    if not dry:
+        nstat = max(1, min(args.steps, 20))
+        for i in range(nstat):
+            step(i, "stats")
+        if n > 1:
+            drain()
+        sync()
+        tot["rays"] = tot["rays"] / nstat * args.steps
     if n > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -513,12 +527,14 @@ def main():
                            "box_tests_per_ray": alg["box_tests_per_ray"], "tri_tests_per_ray": alg["tri_tests_per_ray"],
                            "exact_tri_tests_per_ray": alg["exact_tri_tests_per_ray"],
                            "any_hit_bytes_per_ray": alg["any_bytes_per_ray"],
-                           "any_hit_ms_per_step": tot["any_ms"] / args.steps,
+                           "any_hit_ms_per_step": tot["any_ms"] / max(1, nstat),
                            "note": ("one fused kernel traces the primary AND the shadow rays (generate, closest hit, any hit, shade, "
                                     "pixel): algorithmic bytes of both. " if fused else "") +
-                                   "The scene (4 KB nodes + 100 KB leaf triangles) is cache resident: the algorithmic bytes are "
-                                   "served by the scalar cache / L2, not HBM, and the kernel is bound by vector-instruction issue "
-                                   "(SQ counters: 93 % of the issue slots, profiles/r01_sq_monkey_4k.json); see DESIGN.md"}
+                                   "The scene (the build's BVH over the tree triangles, DESIGN 4.1e: 41 KB of nodes per octant "
+                                   "layout + 46 KB of triangles) is cache resident: the algorithmic bytes are served by the scalar "
+                                   "cache / L2, not HBM, and the kernel is bound by vector-instruction issue (SQ counters: the "
+                                   "vector instructions alone account for the kernel time, profiles/r01_sq_monkey_4k.json); "
+                                   "see DESIGN.md"}
         if not args.no_cpu_baseline and n == 1:      # the CPU leg is timed at N = 1 only
             w, h = (int(x) for x in args.cpu_sample.split("x"))
             out["cpu_baseline"] = cpu_baseline(sd, (w, h))

@@ -222,23 +222,27 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
 int rt_scene_destroy(rt_scene* s);                 /* replaces hw4.cpp:778-783   */
 int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
 
-/* Traversal algorithm of the trace / render entry points (no counterpart: the reference has one loop).
+/* Traversal algorithm of the trace / render entry points (no counterpart: the reference has one loop).  All four
+ * return the reference's hits bit for bit (ids, len, point, occlusion); they differ in the work they do.
  *   RT_TRAVERSAL_STRICT  the reference's visit order, every box and triangle test it performs
- *   RT_TRAVERSAL_FAST    (default) near-first order + culling of subtrees that cannot hold the winner,
+ *   RT_TRAVERSAL_FAST    the reference's tree in near-first order + culling of subtrees that cannot hold the winner,
  *                        ties resolved by the reference's visit rank: same hits, fewer tests
- *   RT_TRAVERSAL_LANE    the fast rules with one path per lane instead of one per wave (per-lane record
- *                        fetches): same hits; slower on coherent rays, faster on incoherent ones
- * The environment variable RT_TRAVERSAL=strict|fast|lane sets the default of new scenes.
- * RT_OPT_LANE_DEPTH: with RT_TRAVERSAL_FAST, rt_render traces the passes of recursion depth >= value (secondary
- * rays and their shadow rays) per lane; default 2 (measured crossover on the 1 M-triangle scene);
- * a value above max_depth keeps every pass wave-synchronous.                                          */
+ *   RT_TRAVERSAL_LANE    one path per lane instead of one per wave (per-lane record fetches, lanes refilled with
+ *                        the launch's next ray): slower on coherent rays, faster on incoherent ones
+ *   RT_TRAVERSAL_BVH     (default) a hierarchy of the build's own over the same triangles; a hit counts only if a
+ *                        reference leaf holding the triangle is reachable for the ray.  Costs about
+ *                        350 B of device memory per tree triangle on top of the reference's tree.
+ * The environment variable RT_TRAVERSAL=strict|fast|lane|bvh sets the default of new scenes.
+ * RT_OPT_LANE_DEPTH: with RT_TRAVERSAL_FAST or RT_TRAVERSAL_BVH, rt_render traces the passes of recursion depth >=
+ * value (secondary rays and their shadow rays) per lane; default 2 (measured crossover on the 1 M-triangle scene,
+ * DESIGN 4.1c); a value above max_depth keeps every pass wave-synchronous.                               */
 #define RT_OPT_TRAVERSAL    1
 #define RT_TRAVERSAL_STRICT 0
 #define RT_TRAVERSAL_FAST   1
 #define RT_TRAVERSAL_LANE   2
 #define RT_TRAVERSAL_BVH    3
 #define RT_OPT_LANE_DEPTH   3
-/* RT_OPT_FUSED_PRIMARY (default 1): with rt_params.primary_only, RT_TRAVERSAL_FAST, one sample per pixel and <= 32
+/* RT_OPT_FUSED_PRIMARY (default 1): with rt_params.primary_only, RT_TRAVERSAL_FAST or _BVH, one sample per pixel and <= 32
  * lights, rt_render runs the whole frame (camera ray, closest hit, shadow rays, shading, pixel) as one kernel instead
  * of the wavefront passes: same bytes, no intermediate arrays.  0 = always the passes.  RT_FUSED_PRIMARY=0|1.       */
 #define RT_OPT_FUSED_PRIMARY 5

@@ -40,7 +40,7 @@ k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles
     // per-wave counts of rays and hits (rt_stats): no barrier, the waves of a block finish at different times
     {
         const unsigned long long m0 = __ballot(inside), m1 = __ballot(hit);
-        if (lane == 0) { wave_pairs[2 * (i >> 6)] = (unsigned)__builtin_popcountll(m0); wave_pairs[2 * (i >> 6) + 1] = (unsigned)__builtin_popcountll(m1); }
+        if (lane == 0 && wave_pairs != nullptr) { wave_pairs[2 * (i >> 6)] = (unsigned)__builtin_popcountll(m0); wave_pairs[2 * (i >> 6) + 1] = (unsigned)__builtin_popcountll(m1); }
     }
 
     HitCtx c;
@@ -81,7 +81,7 @@ k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles
 
 int rtk_primary_only_max_lights() { return PRIMARY_MAX_LIGHTS; }
 
-// d_wave_pairs: 2 unsigned per micro-tile (= per wave)
+// d_wave_pairs: 2 unsigned per micro-tile (= per wave), or NULL when nobody asks for the ray counts
 hipError_t rtk_primary_only(const DevSceneView& sc, const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float eps_f,
                             float ambient, const float bg[3], uint8_t* d_rgb8, int32_t* d_hit_ids, float* d_radiance,
                             unsigned int* d_wave_pairs, int bvh, hipStream_t st) {

@@ -161,13 +161,13 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_trace_closest_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
                           int64_t n, float eps_f, rt_hit* __restrict__ out) {
     bvh_lanes<false>(sc, rays, active, nullptr, n, eps_f, out, nullptr);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_trace_any_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
                       const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
     bvh_lanes<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded);

@@ -116,14 +116,15 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     if (fused) {
         // primary + shadow rays only: the chunk's whole frame in one kernel (kernels_primary.hip); nothing goes through HBM
         // but the pixels.  Timed as the "closest" kernel; there is no separate any-hit launch.
-        const int64_t nblocks = ctiles;                       // one pair of counts per wave
-        void* pairs; RTCHK(s->scratch(S_PAIRS, (size_t)nblocks * 8 + 16, &pairs));
+        const int64_t nblocks = ctiles;                       // one pair of counts per wave, if the caller wants rt_stats
+        void* pairs = nullptr;
+        if (stats) RTCHK(s->scratch(S_PAIRS, (size_t)nblocks * 8 + 16, &pairs));
         ++passes; pass_n.push_back(n0);
         RTCHK(mark());
         HIPCHK(rtk_primary_only(s->view, *cam, c_tiles, ctiles, s->eps_f, p->ambient_intensity, p->background, d_rgb8, d_hit_ids,
                                 s->d_radiance_out, (unsigned int*)pairs, s->fast == 3 ? 1 : 0, st), "k_primary_only");
         RTCHK(mark()); RTCHK(mark()); RTCHK(mark());
-        HIPCHK(rtk_reduce_pairs((const unsigned int*)pairs, nblocks, d_ctr, st), "k_reduce_pairs");
+        if (stats) HIPCHK(rtk_reduce_pairs((const unsigned int*)pairs, nblocks, d_ctr, st), "k_reduce_pairs");
         continue;
     }
     if (drt) {

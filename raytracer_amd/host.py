@@ -195,7 +195,8 @@ class Scene:
             pass
 
     def set_traversal(self, mode):
-        """"strict" (reference order, no culling) or "fast" (default)."""
+        """"strict" (reference order, no culling), "fast" (reference tree, ordered + culled), "lane" (per lane) or "bvh"
+        (the build's own hierarchy, the default): include/rt_hip.h."""
         abi.check(self.L.rt_scene_set_option(self.h, abi.RT_OPT_TRAVERSAL,
                                              {"strict": abi.RT_TRAVERSAL_STRICT, "fast": abi.RT_TRAVERSAL_FAST,
                                               "lane": abi.RT_TRAVERSAL_LANE, "bvh": abi.RT_TRAVERSAL_BVH}[mode]))
