@@ -225,16 +225,20 @@ def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500):
     frame = torch.zeros(BASE_RES[0] * BASE_RES[1] * 3, dtype=torch.uint8, device="cuda")
     st = abi.rt_stats()
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    tot = dict(ms=0.0, closest=0.0, anyh=0.0, rays=0, prim=0)
+    tot = dict(ms=0.0, closest=0.0, anyh=0.0, rays=0, prim=0, shadow=0, any_launches=0)
     for i in range(steps + 1):
         abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(), None, C.byref(st), sp))
         if i:
             tot["ms"] += st.kernel_ms; tot["closest"] += st.trace_closest_ms; tot["anyh"] += st.trace_any_ms
             tot["rays"] += st.rays_primary + st.rays_shadow; tot["prim"] += st.rays_primary
+            tot["shadow"] += st.rays_shadow; tot["any_launches"] += st.trace_any_launches
     alg = algorithmic_bytes_per_ray(gs, cam, params, sp)
     avg_ms = tot["closest"] / steps
-    gbs = alg["bytes_per_ray"] * (tot["prim"] / steps) / (avg_ms * 1e-3) / 1e9
-    traffic = _traffic("mesh_1m.k_trace_closest")
+    fused = tot["any_launches"] == 0 and tot["shadow"] > 0          # the whole frame is one kernel (k_primary_only)
+    bytes_per_launch = alg["bytes_per_ray"] * (tot["prim"] / steps) + (alg["any_bytes_per_ray"] * (tot["shadow"] / steps) if fused else 0.0)
+    gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    kernel = "k_primary_only" if fused else "k_trace_closest"
+    traffic = _traffic("mesh_1m." + kernel)
     # CPU baseline: the oracle port on a strided sample of the same frame (the reference binary would need the scene as
     # 130 MB of text and minutes of KD build printing every node)
     o = ol.OracleScene(sd)
@@ -250,10 +254,13 @@ def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500):
                                      "primary + shadow rays", kd_nodes=int(inf.flat_nodes), leaf_records=int(inf.leaf_refs),
                             scene_device_mb=inf.device_bytes / 1e6, scene_gen_s=gen_s, kd_build_upload_s=build_s),
                 roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
-                              kernel="k_trace_closest", avg_launch_ms=avg_ms, rays_per_launch=tot["prim"] / steps,
+                              kernel=kernel, avg_launch_ms=avg_ms,
+                              rays_per_launch=(tot["prim"] + (tot["shadow"] if fused else 0)) / steps,
                               bytes_per_ray=alg["bytes_per_ray"], box_tests_per_ray=alg["box_tests_per_ray"],
-                              tri_tests_per_ray=alg["tri_tests_per_ray"], any_hit_ms_per_step=tot["anyh"] / steps,
-                              note="algorithmic bytes count every lane's node / triangle reads; the kernel fetches a record once "
+                              tri_tests_per_ray=alg["tri_tests_per_ray"], any_hit_bytes_per_ray=alg["any_bytes_per_ray"],
+                              any_hit_ms_per_step=tot["anyh"] / steps,
+                              note=("one fused kernel traces the primary and the shadow rays: algorithmic bytes of both. " if fused else "") +
+                                   "algorithmic bytes count every lane's node / triangle reads; the kernel fetches a record once "
                                    "per wave on the scalar path, so achieved can exceed what HBM itself delivers"),
                 cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", cores=1, kind="port",
                                   sample=f"the same scene at {res[0]}x{res[1]}, primary + shadow rays, oracle port", seconds=cpu_s))
