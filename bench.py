@@ -399,21 +399,32 @@ def main():
     sd = bench_scene()
     resx, resy = frame_for(n) if not dry else (256 * WEAK_FACTORS.get(n, (n, 1))[0], 128 * WEAK_FACTORS.get(n, (n, 1))[1])
     npix = resx * resy
-    my_pix = torch.from_numpy(rank_pixel_index(resx, resy, rank, n)).to(dev)
-    counts = [len(rank_pixel_index(resx, resy, r, n)) for r in range(n)] if n > 1 else [npix]
-    maxc = max(counts)
-
+    packed = n > 1 and not dry          # a rank's tiles leave the kernel as one contiguous buffer (rt_params.packed_output)
     if not dry:
         gs = host.Scene(sd, device=local_rank)
         cam = host.camera_for(sd, (resx, resy))
-        params = host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n)
+        params = host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n,
+                                     packed_output=1 if packed else 0)
         stream = torch.cuda.current_stream()
         sp = C.c_void_p(stream.cuda_stream)
+    if packed:
+        # pixel lists in the kernel's order (rt_render_pixel_list; -1 = a slot outside the frame)
+        lists = [host.pixel_list(cam, host.default_params("hw4", primary_only=1, tile_size=TILE, tile_rank=r, tile_nranks=n))
+                 for r in range(n)]
+        counts = [int(l.size) for l in lists]
+        my_pix = None
+    else:
+        my_pix = torch.from_numpy(rank_pixel_index(resx, resy, rank, n)).to(dev)
+        counts = [len(rank_pixel_index(resx, resy, r, n)) for r in range(n)] if n > 1 else [npix]
+    maxc = max(counts)
     frame = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
     sendbuf = [torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     recv = [[torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(n)] for _ in range(2)] if (n > 1 and rank == 0) else None
     final = torch.zeros((npix, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
-    all_pix = [torch.from_numpy(rank_pixel_index(resx, resy, r, n)).to(dev) for r in range(n)] if (n > 1 and rank == 0) else None
+    if packed:
+        all_pix = [torch.from_numpy(l.astype(np.int64)).to(dev) for l in lists] if rank == 0 else None
+    else:
+        all_pix = [torch.from_numpy(rank_pixel_index(resx, resy, r, n)).to(dev) for r in range(n)] if (n > 1 and rank == 0) else None
     st = abi.rt_stats()
     tot = dict(rays=0, closest_ms=0.0, any_ms=0.0, closest_launches=0, closest_rays=0, any_launches=0, shadow_rays=0)
     pending = [None, None]
@@ -424,11 +435,14 @@ def main():
         if dry:
             frame.view(-1, 3)[my_pix] = torch.tensor([rank + 1, i & 255, 7], dtype=torch.uint8)
         else:
+            if packed and pending[b] is not None:     # the kernel writes the send buffer itself: its gather of two steps
+                pending[b].wait()                     # ago must have left
+                pending[b] = None
             # timed steps ask for no rt_stats: the frames queue on the stream back to back (rt_stats needs a device -> host
             # copy and a synchronisation per frame).  Every step renders the same frame, so its ray counts are those of the
             # instrumented frames that follow the timed region.
-            abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(), None,
-                                         C.byref(st) if timed == "stats" else None, sp))
+            abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), sendbuf[b].data_ptr() if packed else frame.data_ptr(),
+                                         None, C.byref(st) if timed == "stats" else None, sp))
             if timed == "stats":
                 tot["rays"] += st.rays_primary + st.rays_shadow
                 tot["closest_ms"] += st.trace_closest_ms; tot["any_ms"] += st.trace_any_ms
@@ -437,7 +451,8 @@ def main():
         if n > 1:
             if pending[b] is not None:                # the buffer pair of two steps ago must have left
                 pending[b].wait()
-            sendbuf[b][: counts[rank]] = frame.view(-1, 3)[my_pix]
+            if not packed:
+                sendbuf[b][: counts[rank]] = frame.view(-1, 3)[my_pix]
             pending[b] = dist.gather(sendbuf[b], recv[b] if rank == 0 else None, dst=0, async_op=True)
 
     last = [0]
@@ -451,7 +466,11 @@ def main():
         if rank == 0:
             b = last[0] & 1
             for r in range(n):
-                final[all_pix[r]] = recv[b][r][: counts[r]]
+                if packed:
+                    ok = all_pix[r] >= 0
+                    final[all_pix[r][ok]] = recv[b][r][: counts[r]][ok]
+                else:
+                    final[all_pix[r]] = recv[b][r][: counts[r]]
 
     def sync():
         if not dry:
@@ -516,8 +535,15 @@ def main():
                                       f"{resx}x{resy}, primary + shadow rays only, reflect=refract=0",
                           "frame": [resx, resy], "rays_per_step": total_rays / args.steps,
                           "parallelism": f"tiles{TILE}x{TILE} round-robin over {n} GPU(s), scene replicated, gather to rank 0"}}
+        if n > 1:
+            # the frame rank 0 assembled from the ranks' last gather against the same frame rendered whole on rank 0
+            pw = host.default_params("hw4", primary_only=1)
+            abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(pw), frame.data_ptr(), None, None, sp))
+            torch.cuda.synchronize()
+            out["config"]["assembled_frame_equals_one_gpu_frame"] = bool(torch.equal(final.view(-1), frame))
         # roofline of the dominant kernel (k_trace_closest): algorithmic bytes / HIP-event time
-        alg = algorithmic_bytes_per_ray(gs, cam, params, sp)
+        alg = algorithmic_bytes_per_ray(gs, cam, host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank,
+                                                                      tile_nranks=n), sp)
         launches = max(1, tot["closest_launches"])
         rays_per_launch = tot["closest_rays"] / launches
         avg_ms = tot["closest_ms"] / launches

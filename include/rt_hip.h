@@ -176,7 +176,12 @@ typedef struct rt_params {
     float   focal_distance;     /* distance along the primary ray of the point in focus                         */
     float   light_radius;       /* soft shadows: every light is a ball of this radius, one sample per shadow ray */
     float   glossy;             /* glossy reflection: reflected direction + glossy * (random point in unit ball) */
-    int32_t pad_;
+    int32_t packed_output;      /* rt_render_dev, RT_RENDER_WHITTED only.  1: the colour of the k-th pixel of this call's
+                                   pixel list (rt_render_pixel_list) is written to rgb8[3k] instead of its place in the
+                                   frame, so a rank's share of a tiled frame is one contiguous buffer (coalesced
+                                   writes, no packing before the gather).  rgb8 then holds 3 x 64 x (number of 8x8
+                                   micro-tiles of the call) bytes; hit_ids stay in frame order.  No counterpart in the
+                                   reference (it has one process and one frame).                                   */
 } rt_params;
 
 /* Work counters (the reference keeps checkTime / totalIntersectionCheck,
@@ -402,6 +407,12 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* params,
 int rt_render_dev(rt_scene* s, const rt_camera* cam, const rt_params* params,
                   uint8_t* d_rgb8, int32_t* d_hit_ids, rt_stats* stats,
                   void* hip_stream);
+
+/* The pixel list of a render call: the 8x8 micro-tiles of the tiles this rank owns (tiles in rising number, a tile's
+ * micro-tiles row-major), 64 pixels each (row-major inside the micro-tile).  Writes min(*n, cap) entries
+ * x + y * resx, or -1 for a slot outside the frame, and the full count to *n.  This is the order of
+ * rt_params.packed_output.  Host only; no counterpart in the reference.                                            */
+int rt_render_pixel_list(const rt_camera* cam, const rt_params* p, int32_t* out, int64_t cap, int64_t* n);
 
 /* The frame before quantisation: the `color` the pixel loops hold at hw4.cpp:1105-1109 / final.cpp:1158-1176,
  * float[resx*resy][3], pixel (x,y) at 3*(x + y*resx).  For checking radiance against a tolerance; pixels of

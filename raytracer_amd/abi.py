@@ -59,7 +59,7 @@ class rt_params(C.Structure):
                 ("tile_nranks", _i32), ("gather_samples", _i32), ("knn_k", _i32), ("knn_radius_global", _f),
                 ("knn_radius_caustic", _f), ("irradiance_max_depth", _i32), ("aa_taps", _i32),
                 ("count_work", _i32), ("seed", C.c_uint64), ("spp", _i32), ("lens_radius", _f), ("focal_distance", _f),
-                ("light_radius", _f), ("glossy", _f), ("pad_", _i32)]
+                ("light_radius", _f), ("glossy", _f), ("packed_output", _i32)]
 
 
 class rt_emit_params(C.Structure):
@@ -91,7 +91,7 @@ SYMBOLS = [
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit", "rt_photonmap_emit_dev",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_knn_set", "rt_photon_irradiance", "rt_photon_irradiance_dev",
-    "rt_render", "rt_render_dev", "rt_render_radiance", "rt_generate_primary_dev",
+    "rt_render", "rt_render_dev", "rt_render_radiance", "rt_render_pixel_list", "rt_generate_primary_dev",
 ]
 
 _LIB = None
@@ -143,6 +143,7 @@ def load():
         L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, vp, C.POINTER(rt_stats)]
         L.rt_render_radiance.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, C.POINTER(rt_stats)]
         L.rt_render_dev.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, vp, C.POINTER(rt_stats), vp]
+        L.rt_render_pixel_list.argtypes = [C.POINTER(rt_camera), C.POINTER(rt_params), vp, i64, C.POINTER(i64)]
     if hasattr(L, "rt_photonmap_upload"):
         L.rt_photonmap_upload.argtypes = [vp, i32, vp, i64]
         L.rt_photonmap_build.argtypes = [vp, i32, vp, i64, C.c_float]

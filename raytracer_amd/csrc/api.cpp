@@ -258,6 +258,7 @@ int rt_scene_destroy(rt_scene* s) {
     for (void* p : s->allocs) (void)hipFree(p);
     for (int i = 0; i < RT_NSCRATCH; ++i) if (s->scratch_ptr[i]) (void)hipFree(s->scratch_ptr[i]);
     for (int w = 0; w < 2; ++w) if (s->pmap[w].d_photons) (void)hipFree(s->pmap[w].d_photons);
+    if (s->d_tiles_cache) (void)hipFree(s->d_tiles_cache);
     delete s;
     return RT_OK;
 }

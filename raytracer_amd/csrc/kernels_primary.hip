@@ -17,7 +17,8 @@ template <bool BVH>
 __global__ void __launch_bounds__(256)
 k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntiles, float eps_f,
                float ambient_intensity, float bgr, float bgg, float bgb, uint8_t* __restrict__ rgb8,
-               int32_t* __restrict__ hit_ids, float* __restrict__ radiance_out, unsigned int* __restrict__ wave_pairs) {
+               int32_t* __restrict__ hit_ids, float* __restrict__ radiance_out, unsigned int* __restrict__ wave_pairs,
+               int64_t packed_base) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(i & 63);
     const bool slot = i < ntiles * 64;
@@ -73,7 +74,9 @@ k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles
         cr *= 1.0f; cg *= 1.0f; cb *= 1.0f;                    // the ray's weight (k_shade_lights)
         cr = 0.f + cr; cg = 0.f + cg; cb = 0.f + cb;           // k_accumulate onto the zeroed pixel
     }
-    uint8_t* out = rgb8 + 3 * (size_t)p;
+    // rt_params.packed_output: the pixel goes to its slot in the call's pixel list (coalesced; a rank's share of a
+    // tiled frame is then one contiguous buffer)
+    uint8_t* out = rgb8 + 3 * (size_t)(packed_base >= 0 ? packed_base + i : (int64_t)p);
     if (hit) { out[0] = quantize(cr); out[1] = quantize(cg); out[2] = quantize(cb); }
     else { out[0] = (uint8_t)bgr; out[1] = (uint8_t)bgg; out[2] = (uint8_t)bgb; }
     if (radiance_out) { radiance_out[3 * (size_t)p] = cr; radiance_out[3 * (size_t)p + 1] = cg; radiance_out[3 * (size_t)p + 2] = cb; }
@@ -84,15 +87,15 @@ int rtk_primary_only_max_lights() { return PRIMARY_MAX_LIGHTS; }
 // d_wave_pairs: 2 unsigned per micro-tile (= per wave), or NULL when nobody asks for the ray counts
 hipError_t rtk_primary_only(const DevSceneView& sc, const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float eps_f,
                             float ambient, const float bg[3], uint8_t* d_rgb8, int32_t* d_hit_ids, float* d_radiance,
-                            unsigned int* d_wave_pairs, int bvh, hipStream_t st) {
+                            unsigned int* d_wave_pairs, int bvh, int64_t packed_base, hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
     static const int block = [] { const char* e = getenv("RT_PRIMARY_BLOCK"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();
     const unsigned grid = (unsigned)((ntiles * 64 + block - 1) / block);
     if (bvh)
         hipLaunchKernelGGL(k_primary_only<true>, dim3(grid), dim3(block), 0, st, sc, cam, d_tiles, ntiles, eps_f, ambient, bg[0], bg[1],
-                           bg[2], d_rgb8, d_hit_ids, d_radiance, d_wave_pairs);
+                           bg[2], d_rgb8, d_hit_ids, d_radiance, d_wave_pairs, packed_base);
     else
         hipLaunchKernelGGL(k_primary_only<false>, dim3(grid), dim3(block), 0, st, sc, cam, d_tiles, ntiles, eps_f, ambient, bg[0], bg[1],
-                           bg[2], d_rgb8, d_hit_ids, d_radiance, d_wave_pairs);
+                           bg[2], d_rgb8, d_hit_ids, d_radiance, d_wave_pairs, packed_base);
     return hipGetLastError();
 }

@@ -253,12 +253,12 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
 // GenerateColorImage's pixel write, hw4.cpp:1108-1122.  One thread per primary ray of this rank.
 extern "C" __global__ void __launch_bounds__(256)
 k_finalize(const int32_t* __restrict__ pix0, int64_t n, const float* __restrict__ accum,
-           const uint8_t* __restrict__ hit_any, float bgr, float bgg, float bgb, uint8_t* __restrict__ rgb8) {
+           const uint8_t* __restrict__ hit_any, float bgr, float bgg, float bgb, uint8_t* __restrict__ rgb8, int64_t packed_base) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int p = pix0[i];
     if (p < 0) return;
-    uint8_t* o = rgb8 + 3 * (size_t)p;
+    uint8_t* o = rgb8 + 3 * (size_t)(packed_base >= 0 ? packed_base + i : (int64_t)p);   // rt_params.packed_output
     if (hit_any[p]) {
         o[0] = quantize(accum[3 * (size_t)p]); o[1] = quantize(accum[3 * (size_t)p + 1]); o[2] = quantize(accum[3 * (size_t)p + 2]);
     } else {
@@ -348,9 +348,9 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
 }
 
 hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
-                        uint8_t* rgb8, hipStream_t st) {
+                        uint8_t* rgb8, int64_t packed_base, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_finalize, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum, hit_any, bg[0], bg[1], bg[2], rgb8);
+    hipLaunchKernelGGL(k_finalize, dim3(gridf(n, 256)), dim3(256), 0, st, pix0, n, accum, hit_any, bg[0], bg[1], bg[2], rgb8, packed_base);
     return hipGetLastError();
 }
 

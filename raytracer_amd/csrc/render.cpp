@@ -54,8 +54,21 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     if (p->mode == RT_RENDER_PHOTON) return render_photon_impl(s, cam, p, d_rgb8, d_hit_ids, stats, st);
     if (p->mode != RT_RENDER_WHITTED) return rt_fail(RT_E_INVALID, "rt_render: unknown mode %d", p->mode);
     const int64_t npix = (int64_t)cam->resx * cam->resy;
-    std::vector<int32_t> tiles;
-    rank_microtiles(*cam, *p, tiles);
+    // the rank's micro-tile list: kept from call to call (a frame loop asks for the same list; building and uploading
+    // 130 k entries per 4K frame would cost a fraction of the frame itself)
+    const bool sharded = p->tile_size > 0 && p->tile_nranks > 1;
+    const int key[5] = {cam->resx, cam->resy, sharded ? p->tile_size : 0, sharded ? p->tile_rank : 0, sharded ? p->tile_nranks : 1};
+    bool tiles_fresh = false;
+    if (memcmp(key, s->tiles_key, sizeof key) != 0) {
+        rank_microtiles(*cam, *p, s->tiles_host);
+        memcpy(s->tiles_key, key, sizeof key);
+        tiles_fresh = true;
+    }
+    if (tiles_fresh && s->d_tiles_cache) {                           // the device copy belongs to the old key
+        HIPCHK(hipStreamSynchronize(st), "sync");
+        (void)hipFree(s->d_tiles_cache); s->d_tiles_cache = nullptr;
+    }
+    const std::vector<int32_t>& tiles = s->tiles_host;
     const int64_t ntiles = (int64_t)tiles.size();
     // distributed ray tracing: any of the build-defined samplers switches the sample bookkeeping on
     const int spp = p->spp > 1 ? p->spp : 1;
@@ -71,8 +84,13 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
 
     void *d_tiles = nullptr, *rays0, *pix0, *accum, *hitany, *ctr;
     if (!whole) {
-        RTCHK(s->scratch(S_TILES, (size_t)ntiles * 4, &d_tiles));
-        HIPCHK(hipMemcpyAsync(d_tiles, tiles.data(), (size_t)ntiles * 4, hipMemcpyHostToDevice, st), "copy tiles");
+        if (tiles_fresh || !s->d_tiles_cache) {
+            HIPCHK(hipStreamSynchronize(st), "sync");                 // nothing in flight may still read the old list
+            if (s->d_tiles_cache) { (void)hipFree(s->d_tiles_cache); s->d_tiles_cache = nullptr; }
+            HIPCHK(hipMalloc((void**)&s->d_tiles_cache, (size_t)std::max<int64_t>(ntiles, 1) * 4), "hipMalloc tiles");
+            HIPCHK(hipMemcpy(s->d_tiles_cache, tiles.data(), (size_t)ntiles * 4, hipMemcpyHostToDevice), "copy tiles");
+        }
+        d_tiles = s->d_tiles_cache;
     }
     const int64_t max_n0 = std::min(ntiles, chunk_tiles) * 64 * spp;
     RTCHK(s->scratch(S_RAYS0, (size_t)max_n0 * sizeof(rt_ray), &rays0));
@@ -122,7 +140,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         ++passes; pass_n.push_back(n0);
         RTCHK(mark());
         HIPCHK(rtk_primary_only(s->view, *cam, c_tiles, ctiles, s->eps_f, p->ambient_intensity, p->background, d_rgb8, d_hit_ids,
-                                s->d_radiance_out, (unsigned int*)pairs, s->fast == 3 ? 1 : 0, st), "k_primary_only");
+                                s->d_radiance_out, (unsigned int*)pairs, s->fast == 3 ? 1 : 0, p->packed_output ? tile0 * 64 : -1, st),
+               "k_primary_only");
         RTCHK(mark()); RTCHK(mark()); RTCHK(mark());
         if (stats) HIPCHK(rtk_reduce_pairs((const unsigned int*)pairs, nblocks, d_ctr, st), "k_reduce_pairs");
         continue;
@@ -207,7 +226,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         q_code = (const uint32_t*)ocode;
         n = (int64_t)total;
     }
-    HIPCHK(rtk_finalize(pixlist, nslots, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8, st), "k_finalize");
+    HIPCHK(rtk_finalize(pixlist, nslots, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8,
+                        p->packed_output ? tile0 * 64 : -1, st), "k_finalize");
     if (s->d_radiance_out) HIPCHK(rtk_copy_radiance(pixlist, nslots, (const float*)accum, s->d_radiance_out, st), "k_copy_radiance");
     }   // chunks
     if (stats) {
@@ -245,6 +265,7 @@ int check_args(rt_scene* s, const rt_camera* cam, const rt_params* p, const void
     if (cam->resx <= 0 || cam->resy <= 0 || (int64_t)cam->resx * cam->resy > (int64_t)1 << 30)
         return rt_fail(RT_E_INVALID, "rt_render: bad resolution %dx%d", cam->resx, cam->resy);
     if (p->max_depth < 0 || p->max_depth > 64) return rt_fail(RT_E_INVALID, "rt_render: max_depth out of range");
+    if (p->packed_output && p->mode != RT_RENDER_WHITTED) return rt_fail(RT_E_INVALID, "rt_render: packed_output needs RT_RENDER_WHITTED");
     if (p->tile_nranks > 1 && (p->tile_rank < 0 || p->tile_rank >= p->tile_nranks || p->tile_size <= 0))
         return rt_fail(RT_E_INVALID, "rt_render: bad tile sharding (rank %d of %d, tile %d)", p->tile_rank, p->tile_nranks, p->tile_size);
     return RT_OK;
@@ -260,8 +281,24 @@ extern "C" int rt_render_dev(rt_scene* s, const rt_camera* cam, const rt_params*
     return render_impl(s, cam, p, d_rgb8, d_hit_ids, stats, (hipStream_t)stream);
 }
 
+extern "C" int rt_render_pixel_list(const rt_camera* cam, const rt_params* p, int32_t* out, int64_t cap, int64_t* n) {
+    if (!cam || !p || !n || (cap > 0 && !out)) return rt_fail(RT_E_INVALID, "rt_render_pixel_list: NULL argument");
+    if (cam->resx <= 0 || cam->resy <= 0) return rt_fail(RT_E_INVALID, "rt_render_pixel_list: bad resolution");
+    std::vector<int32_t> tiles;
+    rank_microtiles(*cam, *p, tiles);
+    const int mtw = (cam->resx + 7) / 8;
+    *n = (int64_t)tiles.size() * 64;
+    for (int64_t k = 0; k < *n && k < cap; ++k) {
+        const int t = tiles[(size_t)(k >> 6)], lane = (int)(k & 63);
+        const int x = (t % mtw) * 8 + (lane & 7), y = (t / mtw) * 8 + (lane >> 3);
+        out[k] = (x < cam->resx && y < cam->resy) ? x + y * cam->resx : -1;
+    }
+    return RT_OK;
+}
+
 extern "C" int rt_render_radiance(rt_scene* s, const rt_camera* cam, const rt_params* p, float* radiance, rt_stats* stats) {
     RTCHK(check_args(s, cam, p, radiance));
+    if (p->packed_output) return rt_fail(RT_E_INVALID, "rt_render_radiance: packed_output is for rt_render_dev");
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
     const size_t npix = (size_t)cam->resx * cam->resy;
@@ -280,6 +317,7 @@ extern "C" int rt_render_radiance(rt_scene* s, const rt_camera* cam, const rt_pa
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* rgb8, int32_t* hit_ids,
                          rt_stats* stats) {
     RTCHK(check_args(s, cam, p, rgb8));
+    if (p->packed_output) return rt_fail(RT_E_INVALID, "rt_render: packed_output is for rt_render_dev");
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
     const size_t npix = (size_t)cam->resx * cam->resy;

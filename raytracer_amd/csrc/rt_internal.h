@@ -211,9 +211,10 @@ hipError_t rtk_reduce_pairs(const unsigned int* block_pairs, int64_t nblocks, un
 int rtk_primary_only_max_lights();
 hipError_t rtk_primary_only(const DevSceneView& sc, const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float eps_f,
                             float ambient, const float bg[3], uint8_t* d_rgb8, int32_t* d_hit_ids, float* d_radiance,
-                            unsigned int* d_block_pairs, int bvh, hipStream_t st);
+                            unsigned int* d_block_pairs, int bvh, int64_t packed_base, hipStream_t st);
+// packed_base >= 0 (rt_params.packed_output): pixel slot i is written to rgb8[3 (packed_base + i)] instead of its place in the frame
 hipError_t rtk_finalize(const int32_t* pix0, int64_t n, const float* accum, const uint8_t* hit_any, const float bg[3],
-                        uint8_t* rgb8, hipStream_t st);
+                        uint8_t* rgb8, int64_t packed_base, hipStream_t st);
 hipError_t rtk_copy_radiance(const int32_t* pix0, int64_t n, const float* accum, float* out, hipStream_t st);
 hipError_t rtk_zero_pixels(const int32_t* pix0, int64_t n, float* accum, uint8_t* hit_any, hipStream_t st);
 

@@ -39,6 +39,10 @@ struct rt_scene {
     PhotonMapDev pmap[2];
     float* d_radiance_out = nullptr;  // set for the duration of rt_render_radiance: [resx*resy][3] un-quantised colour
     float* d_dir_tables = nullptr;    // cosTheta, sinTheta, cosPhi, sinPhi [4][256] (photon.cpp:24-27)
+    // the micro-tile list of the last rt_render (a frame loop asks for the same one every time): key, host copy, device copy
+    int tiles_key[5] = {-1, -1, -1, -1, -1};
+    std::vector<int32_t> tiles_host;
+    int32_t* d_tiles_cache = nullptr;
 
     int dev_alloc(void** p, size_t bytes);
     int scratch(int slot, size_t bytes, void** p);

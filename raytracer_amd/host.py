@@ -140,6 +140,17 @@ def default_params(flavour="hw4", **kw):
     return p
 
 
+def pixel_list(cam, params):
+    """rt_render_pixel_list: the pixels (x + y * resx, -1 = outside the frame) of a render call in the order of
+    rt_params.packed_output"""
+    L = abi.load()
+    n = C.c_int64(0)
+    abi.check(L.rt_render_pixel_list(C.byref(cam), C.byref(params), None, 0, C.byref(n)))
+    out = np.empty(n.value, np.int32)
+    abi.check(L.rt_render_pixel_list(C.byref(cam), C.byref(params), out.ctypes.data, n.value, C.byref(n)))
+    return out
+
+
 def final_emit_params(which, seed=1, light=0):
     """the two emission loops of final.cpp:1053-1123: global photons of colour 3 (:1078), caustic photons of
     colour 0.2 (:1115) aimed at the hard-coded proxy sphere (:754-758), Nr 2.40, depth 6 (parameter.h:26)."""

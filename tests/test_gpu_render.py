@@ -96,6 +96,37 @@ def test_tile_sharding_is_byte_identical(gscene, monkey_sd):
         assert np.array_equal(rgb.reshape(136, 200, 3), whole) and np.array_equal(ids, wids)
 
 
+def test_packed_output_is_the_frame_in_pixel_list_order(gscene, monkey_sd):
+    """rt_params.packed_output: a rank's pixels leave the kernel as one contiguous buffer in the order of
+    rt_render_pixel_list; scattered back they are the frame's bytes -- fused kernel and wavefront passes, whole frame
+    and shards, a resolution that is no multiple of 8, and alternating calls (the scene keeps the last tile list)."""
+    import ctypes as C
+    import torch
+    L = gscene.L
+    for res in ((200, 136), (123, 77)):
+        cam = host.camera_for(monkey_sd, res)
+        npix = res[0] * res[1]
+        for kw in (dict(primary_only=1), dict()):
+            whole, _, _ = gscene.render(cam, host.default_params("hw4", **kw))
+            for nranks, ts in ((1, 0), (3, 32), (2, 64)):
+                got = np.full((npix, 3), 9, np.uint8)
+                for r in range(nranks):
+                    p = host.default_params("hw4", tile_size=ts, tile_rank=r, tile_nranks=nranks, packed_output=1, **kw)
+                    pix = host.pixel_list(cam, p)
+                    assert pix.size % 64 == 0
+                    buf = torch.full((pix.size * 3,), 5, dtype=torch.uint8, device="cuda")
+                    abi.check(L.rt_render_dev(gscene.h, C.byref(cam), C.byref(p), buf.data_ptr(), None, None, None))
+                    torch.cuda.synchronize()
+                    b = buf.cpu().numpy().reshape(-1, 3)
+                    ok = pix >= 0
+                    assert (b[~ok] == 5).all()                      # slots outside the frame stay untouched
+                    got[pix[ok]] = b[ok]
+                assert np.array_equal(got.reshape(res[1], res[0], 3), whole), (res, kw, nranks)
+    p = host.default_params("hw4", packed_output=1)
+    with pytest.raises(abi.RtError):
+        gscene.render(host.camera_for(monkey_sd, (64, 64)), p)      # host-buffer entry points refuse it
+
+
 def _glass_scene():
     """floor + wall + a refracting quad and a mirror quad: exercises hw4.cpp:897-924 (both children)."""
     t = ["E 0 0 -1", "V 0 0 1", "F 45", "R 96 96", "L 2 3 -2", "ML -2 2 -1 1 1 1 0.6",
