@@ -608,29 +608,23 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
                 const float va = dv * ri, ta = dt * ri;
                 cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
                 if (__ballot(cand) == 0ull) continue;
-                if (cand) {                                                          // hw4.cpp:211-230, exactly
+                if (cand) {                                                          // hw4.cpp:211-230: the same values, tested together
                     if (COUNT) w->exact += 1;
                     const float detInv = 1.0f / det;
-                    const float u = du * detInv;
-                    if (!(u < 0 || u > 1.0f)) {
-                        const float v = dv * detInv;
-                        if (!(v < 0 || u + v > 1.0f)) {
-                            const float tt = dt * detInv;
-                            if (!(tt < 0)) {
-                                const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
-                                const float len = dist_to(r, px, py, pz);
-                                if (ANY) {
-                                    if (len < far_limit && len >= sc.tol_f && reachable_rank(sc, t->rank, r) != 0x7fffffff) {
-                                        occluded = true; fail = RT_DEAD; hit = false;
-                                    }
-                                } else if (len <= best.len && len >= sc.tol_f &&
-                                           (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
-                                    const int rr = reachable_rank(sc, t->rank, r);
-                                    if (rr != 0x7fffffff && (len < best.len || rr < best.rank)) {
-                                        best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
-                                        best.rank = rr;
-                                    }
-                                }
+                    const float u = du * detInv, v = dv * detInv, tt = dt * detInv;
+                    if (!(u < 0 || u > 1.0f) && !(v < 0 || u + v > 1.0f) && !(tt < 0)) {
+                        const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
+                        const float len = dist_to(r, px, py, pz);
+                        if (ANY) {
+                            if (len < far_limit && len >= sc.tol_f && reachable_rank(sc, t->rank, r) != 0x7fffffff) {
+                                occluded = true; fail = RT_DEAD; hit = false;
+                            }
+                        } else if (len <= best.len && len >= sc.tol_f &&
+                                   (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
+                            const int rr = reachable_rank(sc, t->rank, r);
+                            if (rr != 0x7fffffff && (len < best.len || rr < best.rank)) {
+                                best.len = len; best.prim = t->prim; best.px = px; best.py = py; best.pz = pz;
+                                best.rank = rr;
                             }
                         }
                     }
