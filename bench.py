@@ -139,9 +139,14 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     a["position"][1:] = pos
     a["power"][1:] = np.float32(1.0 / n_photons)
     a["phi"][1:] = rng.integers(0, 256, n_photons); a["theta"][1:] = rng.integers(0, 256, n_photons)
+    del pos, face
+    log(f"kNN: {n_photons} synthetic photons generated, building the heap")
     t0 = time.perf_counter()
     scene_handle.photonmap_build(abi.RT_PMAP_GLOBAL, a)
     build_s = time.perf_counter() - t0
+    log(f"kNN: heap built and uploaded in {build_s:.1f} s")
+    if not with_cpu:
+        del a
     q = rng.uniform(-0.5, 0.5, (n_queries, 3)).astype(np.float32); q[:, 2] += 0.5
     qf = rng.integers(0, 3, n_queries)
     q[qf == 0, 1] = -0.5; q[qf == 1, 0] = -0.5; q[qf == 2, 2] = 1.0
@@ -206,7 +211,7 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
                 cpu_baseline=cpu)
 
 
-def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500):
+def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500, tag="mesh_1m"):
     """BASELINE configuration 3's scene: the synthetic 1 M-triangle mesh (raytracer_amd/synth.py) at 3840x2160,
     primary + shadow rays.  Here the KD-tree (224 k nodes, 2.4 M leaf records, 126 MB per octant-ordered copy set)
     no longer fits any cache, so the HBM roofline of the closest-hit kernel means something."""
@@ -238,7 +243,7 @@ def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500):
     bytes_per_launch = alg["bytes_per_ray"] * (tot["prim"] / steps) + (alg["any_bytes_per_ray"] * (tot["shadow"] / steps) if fused else 0.0)
     gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     kernel = "k_primary_only" if fused else "k_trace_closest"
-    traffic = _traffic("mesh_1m." + kernel)
+    traffic = _traffic(tag + "." + kernel)
     # CPU baseline: the oracle port on a strided sample of the same frame (the reference binary would need the scene as
     # 130 MB of text and minutes of KD build printing every node)
     o = ol.OracleScene(sd)
@@ -371,7 +376,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true", help="skip the secondary lines (kNN, 1M-triangle mesh, photon frame)")
-    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,drt_1m,photon_frame")
+    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,drt_1m,photon_frame (and, on request only: stress_mesh_10m,stress_knn_200m)")
     ap.add_argument("--knn-photons", type=int, default=10_000_000)
     ap.add_argument("--knn-queries", type=int, default=1920 * 1080)
     ap.add_argument("--cpu-sample", type=str, default="960x540")
@@ -576,9 +581,14 @@ def main():
             for name, fn in (("knn", lambda: knn_secondary(gs, torch, args.knn_photons, args.knn_queries)),
                              ("mesh_1m", lambda: mesh_secondary(torch, local_rank)),
                              ("drt_1m", lambda: drt_secondary(torch, local_rank)),
-                             ("photon_frame", lambda: photon_frame_secondary(torch, local_rank))):
+                             ("photon_frame", lambda: photon_frame_secondary(torch, local_rank)),
+                             # one GPU's share of BASELINE configuration 5 (scene and photon map are replicated per GPU)
+                             ("stress_mesh_10m", lambda: mesh_secondary(torch, local_rank, steps=3, nu=3162, nv=1581, tag="stress_mesh_10m")),
+                             ("stress_knn_200m", lambda: knn_secondary(gs, torch, 200_000_000, args.knn_queries, steps=2, with_cpu=False))):
                 if args.only_secondary and name not in args.only_secondary.split(","):
                     continue
+                if name.startswith("stress_") and name not in args.only_secondary.split(","):
+                    continue                      # BASELINE configuration 5's sizes: minutes of host build, on request only
                 try:
                     sec[name] = fn()
                 except Exception as e:           # a secondary line must never take the headline down with it

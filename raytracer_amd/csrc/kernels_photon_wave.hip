@@ -28,8 +28,11 @@
 #include <hipcub/hipcub.hpp>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include "rt_internal.h"
 
+// photons per query above which the per-lane walk is launched (RT_KNN_WALK overrides)
+#define RT_KNN_LANE_RATIO 3.0
 #define W_ALIVE 0x7fffffff
 #define W_DEAD  (-1)
 
@@ -125,7 +128,7 @@ size_t w_align(size_t b) { return (b + 255) & ~(size_t)255; }
 // reference's single split plane, and still exact, see w_boxdist).  Children without children are tested at their
 // parent; the records and boxes of both children are fetched together (contiguous), so a descent waits for one fetch.
 // KMAX >= k + 1.
-template <int KMAX>
+template <int KMAX, bool LANE>
 __global__ void __launch_bounds__(64)
 k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
            const float* __restrict__ nrm3, int64_t q, int k, float maxDist, float* __restrict__ out_rgb,
@@ -148,6 +151,50 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     const bool live = valid && n >= 1;
     bool ambiguous = false;
     unsigned d_p1 = 0, d_v2 = 0, d_c2 = 0, d_v3 = 0, d_m3 = 0, d_lanes = 0;  // measurement (dbg != NULL)
+
+    // LANE: every lane walks the second heap for its own query (a stack of the far children in LDS) instead of the wave
+    // walking the union of its 64 queries' neighbourhoods: the same pruning rule per lane, so the same photons are
+    // seen.  For queries whose neighbourhoods do not overlap (a dense map under sparse queries) the union is 64 walks
+    // long, and every photon on it costs the whole wave a list insertion; per lane, one insertion step serves 64
+    // different photons.  The price: per-lane record fetches instead of wave-uniform ones.
+    __shared__ unsigned lane_stack[LANE ? 32 * 64 : 1];
+    auto child_dist = [&](unsigned c) -> float {                           // lower bound of dist2 over the sub-heap of c
+        if (c <= nb) return w_boxdist(bx[2 * c], bx[2 * c + 1], qx, qy, qz);
+        return w_dist2(*reinterpret_cast<const float4*>(pp + c), qx, qy, qz);   // no children: the photon itself
+    };
+    auto lane_walk = [&](bool start, auto&& bound, auto&& visit, unsigned& steps) {
+        unsigned i = start ? 1u : 0u;
+        int sp = 0;
+        while (__ballot(i != 0u) != 0ull) {
+            ++steps;
+            const bool on = i != 0u;
+            float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on) rec = *reinterpret_cast<const float4*>(pp + i);
+            visit(rec, i, on);
+            unsigned next = 0u;
+            if (on) {
+                const unsigned c0 = 2u * i;
+                if (c0 <= un) {
+                    const bool has_r = c0 + 1u <= un;
+                    const float dl = child_dist(c0), dr = has_r ? child_dist(c0 + 1u) : 0.f;
+                    const float bd = bound();
+                    const bool wl = dl <= bd, wr = has_r && dr <= bd;
+                    if (wl && wr) {
+                        const bool left_first = dl <= dr;
+                        lane_stack[sp * 64 + lane] = left_first ? c0 + 1u : c0; ++sp;
+                        next = left_first ? c0 : c0 + 1u;
+                    } else if (wl) next = c0;
+                    else if (wr) next = c0 + 1u;
+                }
+                while (next == 0u && sp > 0) {                             // the nearest deferred child the lane still wants
+                    --sp;
+                    const unsigned c = lane_stack[sp * 64 + lane];
+                    if (child_dist(c) <= bound()) next = c;
+                }
+            }
+            i = next;
+        }
+    };
 
     // ---- phase 2: the k+1 smallest dist2 of S per lane ---------------------------------------------------------
     int reg[KMAX];                                                         // bit patterns of dist2, ascending
@@ -198,6 +245,9 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 tau = tau < far ? tau : far;
             }
         };
+        if (LANE) {
+            lane_walk(live, [&]() { return tau; }, [&](const float4& r4, unsigned, bool on) { visit(r4, on); }, d_v2);
+        } else {
         int fail = live ? W_ALIVE : W_DEAD;
         unsigned i = 1, pending = 0;
         int depth = 0;
@@ -250,6 +300,7 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 if (__ballot(fail == W_ALIVE) != 0ull) break;
             }
             if (done) break;
+        }
         }
     }
     // a wave whose walk does not end (64 queries that are not neighbours after all) gives up and leaves its queries to
@@ -325,6 +376,9 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 if (member && (dx * nx + dy * ny + dz * nz) < 0.0f) { r += w4.x; g += w4.y; b += w4.z; }
             }
         };
+        if (LANE) {
+            lane_walk(summing, [&]() { return T; }, visit, d_v3);
+        } else {
         int fail = summing ? W_ALIVE : W_DEAD;
         unsigned i = 1, pending = 0;
         int depth = 0;
@@ -374,6 +428,7 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 if (__ballot(fail == W_ALIVE) != 0ull) break;
             }
             if (done) break;
+        }
         }
         if (summing && members != found) ambiguous = true;                 // more (or fewer) photons within T than k: a tie
         const float tmp = (float)(((double)1.0f / 3.141592) / (double)T);  // (1.0f/PI)/(np.dist2[0])
@@ -445,7 +500,6 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
     static const int group_env = getenv("RT_KNN_GROUP") ? atoi(getenv("RT_KNN_GROUP")) : 0;
     int group = q >= 64 * 8192 ? 64 : (q >= 32 * 8192 ? 32 : (q >= 16 * 4096 ? 16 : 8));
     if (group_env == 64 || group_env == 32 || group_env == 16 || group_env == 8) group = group_env;
-    const unsigned grid = (unsigned)((q + group - 1) / group);
     static const bool no_sort = getenv("RT_KNN_NOSORT") != nullptr;
     const int32_t* perm = nullptr;
     if (q > 64 && !no_sort) {
@@ -464,11 +518,25 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
     // ends when its longest wave does, and the strict kernel spreads the 64 queries over 16 waves.
     static const unsigned budget_env = getenv("RT_KNN_BUDGET") ? (unsigned)atoi(getenv("RT_KNN_BUDGET")) : 0u;
     const unsigned budget = budget_env ? budget_env : 16384u;
-#define WAVE_ARGS dim3(grid), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_redo_list, d_redo_count, perm, budget, group, d_stats
-    if (k <= 31) hipLaunchKernelGGL(k_irr_main<32>, WAVE_ARGS);
-    else if (k <= 63) hipLaunchKernelGGL(k_irr_main<64>, WAVE_ARGS);
-    else if (k <= 103) hipLaunchKernelGGL(k_irr_main<104>, WAVE_ARGS);
-    else hipLaunchKernelGGL(k_irr_main<128>, WAVE_ARGS);
+    // which walk: RT_KNN_WALK=wave|lane (read at every call), else by the photons per query: above 3 the queries'
+    // neighbourhoods hardly overlap and the per-lane walk wins (10 M photons under 2.07 M queries: 117 against 104 M
+    // lookups/s; 200 M photons: 74 against 20; the photon frame's 1 M-photon map under denser queries: 70 against 79)
+    const int walk_env = [] { const char* e = getenv("RT_KNN_WALK"); return !e ? 0 : (strcmp(e, "lane") == 0 ? 2 : (strcmp(e, "wave") == 0 ? 1 : 0)); }();
+    const bool lane_walk = walk_env ? walk_env == 2 : (double)n > RT_KNN_LANE_RATIO * (double)q;
+    if (lane_walk) { group = 64; }
+    const unsigned grid2 = (unsigned)((q + group - 1) / group);
+#define WAVE_ARGS dim3(grid2), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_redo_list, d_redo_count, perm, budget, group, d_stats
+    if (lane_walk) {
+        if (k <= 31) hipLaunchKernelGGL((k_irr_main<32, true>), WAVE_ARGS);
+        else if (k <= 63) hipLaunchKernelGGL((k_irr_main<64, true>), WAVE_ARGS);
+        else if (k <= 103) hipLaunchKernelGGL((k_irr_main<104, true>), WAVE_ARGS);
+        else hipLaunchKernelGGL((k_irr_main<128, true>), WAVE_ARGS);
+    } else {
+        if (k <= 31) hipLaunchKernelGGL((k_irr_main<32, false>), WAVE_ARGS);
+        else if (k <= 63) hipLaunchKernelGGL((k_irr_main<64, false>), WAVE_ARGS);
+        else if (k <= 103) hipLaunchKernelGGL((k_irr_main<104, false>), WAVE_ARGS);
+        else hipLaunchKernelGGL((k_irr_main<128, false>), WAVE_ARGS);
+    }
 #undef WAVE_ARGS
     return hipGetLastError();
 }

@@ -21,13 +21,22 @@ def _load(name):
         return {k: np.ascontiguousarray(z[k]) for k in z.files}
 
 
-@pytest.fixture(scope="module", params=["fast", "strict"])
+@pytest.fixture(scope="module", params=["fast", "fast-wave", "fast-lane", "strict"])
 def gscene(request):
+    """fast = the default choice between the wave-shared and the per-lane walk (by photons per query); the two are also
+    forced through RT_KNN_WALK, which the library reads at every call"""
     sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
     s = host.Scene(sd)
-    s.set_knn(request.param)
-    s.knn_mode = request.param
+    mode, _, walk = request.param.partition("-")
+    s.set_knn(mode)
+    s.knn_mode = mode
+    old = os.environ.pop("RT_KNN_WALK", None)
+    if walk:
+        os.environ["RT_KNN_WALK"] = walk
     yield s
+    os.environ.pop("RT_KNN_WALK", None)
+    if old is not None:
+        os.environ["RT_KNN_WALK"] = old
     s.close()
 
 
