@@ -128,7 +128,7 @@ def cpu_baseline(sd, res):
 
 def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, steps=3, with_cpu=True):
     """BASELINE configuration 4's shape: kNN radiance lookups/s on a synthetic photon map (positions on
-    the walls of the Final scene's unit box; GPU emission is not built yet), queries on the floor/walls."""
+    the walls of the Final scene's unit box), queries on the floor/walls."""
     from raytracer_amd import abi
     rng = np.random.default_rng(1234)
     a = np.zeros(n_photons + 1, abi.photon_dtype)

@@ -261,7 +261,9 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
  *                  its list code evicts; rt_photon_knn_set: 16 lanes per query with the reference's
  *                  visits.  Queries whose set depends on the reference's heap history (exact ties),
  *                  and waves whose walk does not end within its budget, are redone strictly.  The irradiance adds the same photons in
- *                  another order: equal up to float association (<= 1e-5 relative in the tests).
+ *                  another order: equal up to float association (<= 1e-5 relative in the tests).  Above 3 photons
+ *                  per query of a call every lane walks the second heap for its own query instead of sharing
+ *                  the walk (the neighbourhoods no longer overlap); RT_KNN_WALK=wave|lane forces either.
  * RT_KNN=strict|fast sets the default of new scenes.                                                          */
 #define RT_OPT_KNN          2
 #define RT_KNN_STRICT       0

@@ -168,6 +168,7 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
         while (__ballot(i != 0u) != 0ull) {
             ++steps;
             const bool on = i != 0u;
+            if (dbg) d_lanes += (unsigned)__popcll(__ballot(on));
             float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
             if (on) rec = *reinterpret_cast<const float4*>(pp + i);
             visit(rec, i, on);
