@@ -14,7 +14,7 @@
 #define PRIMARY_MAX_LIGHTS 32
 
 template <bool BVH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntiles, float eps_f,
                float ambient_intensity, float bgr, float bgg, float bgb, uint8_t* __restrict__ rgb8,
                int32_t* __restrict__ hit_ids, float* __restrict__ radiance_out, unsigned int* __restrict__ wave_pairs,
