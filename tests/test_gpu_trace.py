@@ -176,3 +176,47 @@ def test_exact_ties_resolve_like_the_reference_order():
         _assert_hits_equal(g.trace_closest(rays), want)
         g.close()
     o.close()
+
+
+def _grazing_rays(sd, n, seed):
+    """rays that lie almost IN the plane of a triangle and pass near it: where the reference's rounded u / v / t accept
+    hits well outside the triangle (|det| just above the 1e-6 cut-off), i.e. where the culling slack of the fast modes
+    (lateral_slack) has to be wide enough."""
+    rng = np.random.default_rng(seed)
+    tri = sd.prims[:, :9].reshape(-1, 3, 3).astype(np.float64)
+    t = tri[rng.integers(0, tri.shape[0], n)]
+    e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+    nrm = np.cross(e1, e2); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    uv = rng.uniform(-0.6, 1.6, (n, 2))
+    p = t[:, 0] + uv[:, :1] * e1 + uv[:, 1:] * e2                      # a point in the plane, in or near the triangle
+    a = rng.uniform(0, 2 * np.pi, n)[:, None]
+    b1 = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), 1e-300)
+    b2 = np.cross(nrm, b1)
+    inplane = np.cos(a) * b1 + np.sin(a) * b2
+    tilt = (10.0 ** rng.uniform(-7, -1.5, n) * rng.choice([-1.0, 1.0], n))[:, None]
+    d = inplane + tilt * nrm
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = (10.0 ** rng.uniform(-1, 1.5, n))[:, None]
+    o = p - dist * d
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("which", ["monkey", "soup"])
+def test_grazing_rays_agree_across_traversals(which, monkey_sd):
+    """1.5 M rays a fraction of a degree off a triangle's plane, from 0.1 to 30 units away: every traversal returns the
+    strict one's hit, bit for bit (the strict one is the reference's loop, pinned by the tests above).  On a sample the
+    oracle is asked as well."""
+    sd = monkey_sd if which == "monkey" else _soup_scene(3000, 31)
+    rays = _grazing_rays(sd, 1_500_000, 11)
+    g = host.Scene(sd); g.set_traversal("strict")
+    want = g.trace_closest(rays); want_any = g.trace_any(rays)
+    assert (want["prim"] >= 0).sum() > 100_000
+    o = ol.OracleScene(sd)
+    sel = np.arange(0, rays.shape[0], 97)
+    _assert_hits_equal(want[sel], o.trace_closest(rays[sel]))
+    o.close()
+    for mode in ("fast", "lane", "bvh"):
+        g.set_traversal(mode)
+        _assert_hits_equal(g.trace_closest(rays), want)
+        assert np.array_equal(g.trace_any(rays), want_any), mode
+    g.close()
