@@ -404,10 +404,10 @@ def main():
     sd = bench_scene()
     resx, resy = frame_for(n) if not dry else (256 * WEAK_FACTORS.get(n, (n, 1))[0], 128 * WEAK_FACTORS.get(n, (n, 1))[1])
     npix = resx * resy
-    packed = n > 1 and not dry          # a rank's tiles leave the kernel as one contiguous buffer (rt_params.packed_output)
+    packed = n > 1                      # a rank's tiles leave the kernel as one contiguous buffer (rt_params.packed_output)
+    cam = host.camera_for(sd, (resx, resy))
     if not dry:
         gs = host.Scene(sd, device=local_rank)
-        cam = host.camera_for(sd, (resx, resy))
         params = host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n,
                                      packed_output=1 if packed else 0)
         stream = torch.cuda.current_stream()
@@ -437,7 +437,16 @@ def main():
     def step(i, timed):
         b = i & 1
         last[0] = i
-        if dry:
+        if dry and packed:
+            # what the kernel would write: slot k of this rank's pixel list gets the colour of its pixel (here a
+            # function of the pixel index, the rank and the step, so that the assembled frame can be checked exactly)
+            if pending[b] is not None:
+                pending[b].wait(); pending[b] = None
+            pix = torch.from_numpy(lists[rank].astype(np.int64))
+            sendbuf[b][: counts[rank], 0] = (pix % 251).to(torch.uint8)
+            sendbuf[b][: counts[rank], 1] = rank + 1
+            sendbuf[b][: counts[rank], 2] = i & 255
+        elif dry:
             frame.view(-1, 3)[my_pix] = torch.tensor([rank + 1, i & 255, 7], dtype=torch.uint8)
         else:
             if packed and pending[b] is not None:     # the kernel writes the send buffer itself: its gather of two steps
@@ -520,7 +529,13 @@ def main():
     if dry:
         if rank == 0:
             if n > 1:
-                ok = all(bool((final[all_pix[r]][:, 0] == r + 1).all()) for r in range(n))
+                ok = True
+                for r in range(n):
+                    pix = all_pix[r][all_pix[r] >= 0]
+                    got = final[pix]
+                    ok = ok and bool((got[:, 0] == (pix % 251).to(torch.uint8)).all()) and bool((got[:, 1] == r + 1).all()) \
+                        and bool((got[:, 2] == (last[0] & 255)).all())
+                ok = ok and sum(int((all_pix[r] >= 0).sum()) for r in range(n)) == npix      # every pixel has exactly one owner
             else:
                 ok = True
             print(json.dumps({"dry_run": True, "n_gpus": n, "frame": [resx, resy], "assembled_ok": ok,
