@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""one-off confidence run for the culling slack: many batches of near-in-plane rays, bvh / fast / lane against
-strict on the GPU, on three scenes; prints the number of rays compared and of mismatches (expected: 0)"""
+"""one-off confidence run for the culling slack, not collected by pytest: many batches of near-in-plane rays,
+bvh / fast / lane against strict on the GPU, on three scenes; prints the number of rays compared and of mismatches
+(expected: 0).  Run as `python tests/grazing_campaign.py [batches]` on a GPU box."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import bench
 from raytracer_amd import host, synth
