@@ -3,8 +3,9 @@
 // The reference's KD-tree (scene_build.cpp) decides WHICH triangles a ray may hit: only those in a leaf whose chain of
 // boxes the ray passes (KDNode::HitTest, hw4.cpp:281-328).  It is a poor index, though (monkey: leaves of ~30
 // overlapping triangles, every triangle in 2.2 leaves, 42 box + 66 triangle tests per primary ray).  This file builds
-// a second index over the same triangles -- a binary BVH, median splits of the centroids, <= RT_GROUP triangles per
-// leaf, every triangle once -- that the fast traversal walks instead; a hit found through it counts only if the
+// a second index over the same triangles -- a binary BVH, binned-SAH splits (triangles much larger than their node's
+// median first go to a child of their own), <= RT_GROUP triangles per leaf, every triangle once -- that the default
+// traversal walks instead; a hit found through it counts only if the
 // reference could have found it, which the device checks per accepted hit against the reference's own boxes
 // (trace_device.h: reachable_rank).  What is kept per triangle for that check: the reference leaves that hold it, in
 // the reference's visit order.
