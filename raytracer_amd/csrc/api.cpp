@@ -206,6 +206,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.nbvh = (int32_t)flat.bvh_nodes[0].size();
     memcpy(v.bvh_root_centre, flat.bvh_root_centre, sizeof v.bvh_root_centre);
     v.bvh_root_rho = v.nbvh > 0 ? flat.bvh_nodes[0][0].rho : 0.f;
+    // per-lane walks all use layout 0: with random directions the eight layouts are eight times the cache footprint,
+    // which costs more than the near-first order saves (1M-triangle mesh, passes of depth >= 2: 18 % faster than with
+    // the ray's own octant; RT_LANE_LAYOUT_MASK=7 restores that)
+    v.lane_layout_mask = 0;
+    if (const char* e = getenv("RT_LANE_LAYOUT_MASK")) v.lane_layout_mask = atoi(e) & 7;
     if (!rc) {
         void* q = nullptr;
         if (hipMalloc(&q, 64) != hipSuccess) rc = rt_fail(RT_E_NOMEM, "hipMalloc failed");

@@ -121,6 +121,7 @@ struct DevSceneView {       // passed by value to kernels
     float bvh_root_centre[3];           // what DevBvhNode::rho is measured from (the root box's centre, rounded)
     float bvh_root_rho;                 // rho of the root node
     uint32_t* ray_counter;              // next ray of a k_trace_*_bvh_lanes launch (zeroed by the launcher)
+    int32_t lane_layout_mask;           // per-lane walks use layout (octant & mask): 0 = one layout for all (default), 7 = the ray's own octant
     const DevLeafTri* bvh_tris;         // every tree triangle once; .rank = its index t into bvh_tri_ref
     const int32_t* bvh_tri_ref;         // [t][2]: first, count into bvh_ref_leaf
     const DevRefLeaf* bvh_ref_leaf;     // the reference leaves holding triangle t, by rising rank

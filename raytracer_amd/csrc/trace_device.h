@@ -650,7 +650,7 @@ __device__ __forceinline__ void bvh_lane_start(const DevSceneView& sc, const Ray
     const int oct = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
     const DevBvhNode* nodes = sc.bvh_oct[0];
 #pragma unroll
-    for (int o = 1; o < 8; ++o) if (oct == o) nodes = sc.bvh_oct[o];
+    for (int o = 1; o < 8; ++o) if ((oct & sc.lane_layout_mask) == o) nodes = sc.bvh_oct[o];
     wk.r = r; wk.nodes = nodes; wk.i = 0; wk.far_limit = far_limit;
     wk.bc = bvh_consts(sc, r, aux, sc.bvh_root_rho);
 }
