@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from raytracer_amd import host, scene
+from raytracer_amd import abi, host, scene
 
 pytestmark = pytest.mark.gpu
 
@@ -220,3 +220,31 @@ def test_grazing_rays_agree_across_traversals(which, monkey_sd):
         _assert_hits_equal(g.trace_closest(rays), want)
         assert np.array_equal(g.trace_any(rays), want_any), mode
     g.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict", "lane", "bvh"])
+def test_tree_triangles_and_loose_spheres_together(mode, monkey_sd):
+    """an `O` object (KD-tree, and the build's BVH over it) next to spheres, which are tested one by one after the trees
+    (hw4.cpp:808-871 visits objects first, then the sphere list): closest hit with the strict-< rule between the two
+    kinds, any hit; in lane mode the scene has loose primitives, so the reference-tree lane kernel takes every ray."""
+    from raytracer_amd.scene import SceneData
+    base = _soup_scene(600, 5, nobj=2)
+    n = base.prims.shape[0]
+    sph = np.zeros((3, base.prims.shape[1]), np.float32)
+    sph[:, :4] = [[0.1, 0.0, 0.6, 0.25], [-0.3, 0.2, 0.9, 0.15], [0.0, -0.45, 0.5, 0.1]]
+    prims = np.concatenate([base.prims, sph])
+    ptype = np.concatenate([np.zeros(n, np.uint8), np.full(3, abi.RT_PRIM_SPHERE, np.uint8)])
+    sd = SceneData(prims=prims, prim_type=ptype, prim_material=np.zeros(n + 3, np.int32), materials=base.materials,
+                   obj_first=base.obj_first, obj_count=base.obj_count, lights=base.lights, eye=base.eye, view=base.view,
+                   fov=45.0, resx=64, resy=64)
+    g = host.Scene(sd); g.set_traversal(mode)
+    assert g.info().nloose == 3 and g.info().flat_nodes > 0
+    o = ol.OracleScene(sd)
+    rays = np.concatenate([_random_rays(20000, 3, box=0.7), _primary_rays(sd, 96, 96), _edge_rays()])
+    want = o.trace_closest(rays)
+    assert (want["prim"] >= n).sum() > 500 and ((want["prim"] >= 0) & (want["prim"] < n)).sum() > 500
+    _assert_hits_equal(g.trace_closest(rays), want)
+    assert np.array_equal(g.trace_any(rays), o.trace_any(rays))
+    tmax = np.random.default_rng(8).uniform(0.02, 1.5, rays.shape[0]).astype(np.float32)
+    assert np.array_equal(g.trace_any(rays, tmax), o.trace_any(rays, tmax))
+    g.close(); o.close()
