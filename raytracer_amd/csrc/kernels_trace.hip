@@ -105,14 +105,14 @@ k_trace_any_lane(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t
 // Per-lane walk of the build's own hierarchy with lanes refilled from the launch's rays (trace_device.h: BvhLaneWalk):
 // a fixed number of waves; a lane whose ray is finished writes its result and takes the next unclaimed ray.  Rays that
 // traverse_bvh does not take (zero / non-finite components, not unit length) are left for k_trace_*_lane; inactive
-// rays get the "no hit" result here.  Needs nbvh > 0 and nloose == 0 (the launchers check).
+// rays get the "no hit" result here.  Needs nbvh > 0 (the launchers check).
 template <bool ANY>
 __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
                                           const float* __restrict__ tmax, int64_t n, float eps_f,
                                           rt_hit* __restrict__ out, uint8_t* __restrict__ occluded) {
     const int lane = threadIdx.x & 63;
     const bool use_tmax = tmax != nullptr;
-    bool have = false, more = true, occ = false;
+    bool have = false, more = true, occ = false, fresh = false;
     int64_t idx = 0;
     BvhLaneWalk wk; wk.i = 0; wk.far_limit = 0.f; wk.nodes = sc.bvh_oct[0];
     wk.r = Rayf{0, 0, 0, 0, 0, 1};
@@ -138,11 +138,19 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
                     const Rayf r = load_ray(rays, my);
                     const RayAux aux = ray_aux(r);
                     if (bvh_fit(aux)) {
-                        idx = my; have = true; occ = false;
+                        idx = my; have = true; occ = false; fresh = true;
                         best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
                         bvh_lane_start(sc, r, aux, ANY ? (use_tmax ? tmax[my] : 1e9f) : 0.f, wk);
                     }
                 }
+            }
+            // primitives outside the trees (spheres), for the rays just taken.  The reference tests them after the trees
+            // and keeps an equal-len tree hit; testing them first gives the same answer because a tree hit of equal len
+            // still replaces them (their rank stays 0x7fffffff), and their len already bounds the walk.
+            if (sc.nloose > 0 && __ballot(fresh) != 0ull) {
+                loose_prims<ANY>(sc, wk.r, fresh, eps_f, wk.far_limit, use_tmax, best, occ);
+                if (ANY && fresh && occ) wk.i = sc.nbvh;             // occluded already: nothing to walk
+                fresh = false;
             }
         }
         if (__ballot(have) == 0ull) { if (__ballot(more) == 0ull) break; continue; }
@@ -327,7 +335,7 @@ static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + b
 // the refilling per-lane BVH kernels: RT_LANE_BVH=0 keeps the reference-tree walk for every ray
 static inline int bvh_lanes_usable(const DevSceneView& sc) {
     static const int on = [] { const char* e = getenv("RT_LANE_BVH"); return e ? atoi(e) : 1; }();
-    return (on && sc.nbvh > 0 && sc.nloose == 0 && sc.ray_counter != nullptr) ? 1 : 0;
+    return (on && sc.nbvh > 0 && sc.ray_counter != nullptr) ? 1 : 0;
 }
 // waves of a refilling kernel: enough to fill the chip several times over, never more than the rays need
 static inline unsigned lanes_grid(int64_t n) {

@@ -226,7 +226,8 @@ def test_grazing_rays_agree_across_traversals(which, monkey_sd):
 def test_tree_triangles_and_loose_spheres_together(mode, monkey_sd):
     """an `O` object (KD-tree, and the build's BVH over it) next to spheres, which are tested one by one after the trees
     (hw4.cpp:808-871 visits objects first, then the sphere list): closest hit with the strict-< rule between the two
-    kinds, any hit; in lane mode the scene has loose primitives, so the reference-tree lane kernel takes every ray."""
+    kinds, any hit; the refilling per-lane kernels test the spheres when a lane takes its ray (a tree hit of equal len
+    still wins)."""
     from raytracer_amd.scene import SceneData
     base = _soup_scene(600, 5, nobj=2)
     n = base.prims.shape[0]
