@@ -372,8 +372,8 @@ def _traffic(key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true", help="skip the secondary lines (kNN, 1M-triangle mesh, photon frame)")
     ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,drt_1m,photon_frame (and, on request only: stress_mesh_10m,stress_knn_200m)")
