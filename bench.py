@@ -93,6 +93,35 @@ def algorithmic_bytes_per_ray(gs, cam, params, sp):
                 any_tri_tests_per_ray=atri)
 
 
+def _port_frame(args):
+    """one oracle-port frame in a worker process (cpu_baseline's all-cores leg)"""
+    sd, res = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from raytracer_amd import host
+    o = ol.OracleScene(sd)
+    t0 = time.perf_counter()
+    o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *res), host.default_params("hw4", primary_only=1))
+    dt = time.perf_counter() - t0
+    rays = o.counters().rays_traced
+    o.close()
+    return rays, dt
+
+
+def cpu_port_all_cores(sd, res):
+    """the build's CPU restatement on all host cores.  Rays are independent, so the cores each render the
+    sample frame (one process per core, fork); throughput = all their rays over the wall time of the slowest."""
+    import multiprocessing as mp
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), os.cpu_count() or 1, 64))
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res_list = pool.map(_port_frame, [(sd, res)] * cores)
+    wall = time.perf_counter() - t0
+    rays = sum(r for r, _ in res_list)
+    return dict(value=rays / wall / 1e6, unit="Mrays/s", cores=cores, kind="port",
+                sample=f"{cores} processes, each the sample frame {res[0]}x{res[1]} (oracle port)", seconds=wall)
+
+
 def cpu_baseline(sd, res):
     """The reference binary (oracle/_ref/hw4_ref, compiled from the reference's own sources in the build
     container) on a bounded sample of the same workload: same scene, same materials, `R` lowered to `res`.
@@ -591,6 +620,10 @@ def main():
         if not args.no_cpu_baseline and n == 1:      # the CPU leg is timed at N = 1 only
             w, h = (int(x) for x in args.cpu_sample.split("x"))
             out["cpu_baseline"] = cpu_baseline(sd, (w, h))
+            try:
+                out["cpu_baseline"]["all_cores"] = cpu_port_all_cores(sd, (w, h))
+            except Exception as e:      # a reported extra, never a reason to lose the line
+                out["cpu_baseline"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_knn and n == 1:
             sec = {}
             for name, fn in (("knn", lambda: knn_secondary(gs, torch, args.knn_photons, args.knn_queries)),
