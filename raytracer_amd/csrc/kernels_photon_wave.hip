@@ -329,7 +329,7 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
         int acc = 0;
         float m2 = -1.f;
         unsigned i = 1, child = 0;
-        bool up = false;
+        bool up = false, beyond = false;
         for (;;) {
             const float4 rec = *reinterpret_cast<const float4*>(ph + i);
             ++d_p1;
@@ -342,13 +342,17 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
             const float d2 = w_dist2(rec, qx, qy, qz);                     // both subtrees done: the node itself
             if (d2 < r0) {
                 if (++acc > k) break;
+                // one of the first k accepted lies beyond the k-th nearest: then so does E (the farthest of them), T is
+                // the k-th nearest's dist2 and E is no member -- which photon E is no longer matters
+                if (d2 > kth) { beyond = true; break; }
                 if (d2 > dE) { m2 = dE; dE = d2; E = (int)i; }
                 else if (d2 > m2) m2 = d2;
             }
             if (i == 1) break;
             child = i; i >>= 1; up = true;
         }
-        if (acc <= k || dE == m2) ambiguous = true;                        // (cannot happen) / two candidates for E
+        if (beyond) { E = -1; dE = 3.0e38f; }
+        else if (acc <= k || dE == m2) ambiguous = true;                   // (cannot happen) / two candidates for E
     }
     // S \ {E}: if E is one of the k nearest, the (k+1)-th nearest takes its place
     const int found = evict ? k : cnt;
