@@ -80,10 +80,19 @@ __device__ __forceinline__ bool load_hit(const DevSceneView& sc, const rt_ray* _
     return true;
 }
 
-// one vector atomic per block and counter
+// one vector atomic per block and counter (every thread of the block must call it: it synchronises).  Atomics of many
+// waves on one address serialise, so this stays out of kernels with a thread per shadow ray.
 __device__ __forceinline__ void block_add(unsigned long long* ctr, unsigned v) {
+    __shared__ unsigned part[16];
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, (unsigned long long)v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (unsigned w2 = 0; w2 < (blockDim.x + 63) / 64; ++w2) t += part[w2];
+        if (t) atomicAdd(ctr, (unsigned long long)t);
+    }
+    __syncthreads();
 }
 
 }  // namespace
@@ -219,7 +228,9 @@ k_pm_shadow(DevSceneView sc, const rt_hit* __restrict__ hits, const int32_t* __r
     else traverse<true>(sc, r, valid, eps_f, tLight, true, best, o);
     loose_prims<true>(sc, r, valid, eps_f, tLight, true, best, o);
     if (i < n) occ[t] = o ? 1 : 0;
-    block_add(ctr + PMC_SHADOW, valid ? 1u : 0u);
+    // no counter here: one atomic per wave on one address (180 000 waves per launch) cost ten times the kernel's work;
+    // the shadow rays are S per counted hit (PMC_HITS, same predicate), which the host multiplies out
+    (void)ctr;
 }
 
 // caustic term (final.cpp:909-910) + direct illumination over every light's sample grid with the reference's

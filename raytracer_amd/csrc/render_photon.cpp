@@ -197,7 +197,7 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
         memset(stats, 0, sizeof *stats);
         stats->rays_primary = (int64_t)h[0]; stats->rays_gather = (int64_t)h[2];
         stats->rays_reflect = (int64_t)h[3]; stats->rays_refract = (int64_t)h[4];
-        stats->rays_shadow = (int64_t)h[7];
+        stats->rays_shadow = (int64_t)h[1] * S;                   // k_pm_shadow: S rays per eye-path hit
         stats->knn_lookups = (int64_t)h[5] + (int64_t)h[1];       // global lookups + one caustic lookup per eye-path hit
         stats->passes = passes; stats->kernel_ms = ms;
     }
