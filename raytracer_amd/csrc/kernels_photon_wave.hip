@@ -70,7 +70,7 @@ __device__ __forceinline__ float w_boxdist(const float4& lo, const float4& hi, f
 // v_min_i32 / v_max_i32 need no NaN canonicalisation.  Blocks whose last entry no lane undercuts are skipped.
 template <int KMAX>
 __device__ __forceinline__ void w_insert(int (&reg)[KMAX], int x) {
-    constexpr int NB = 4, KB = KMAX / NB;
+    constexpr int NB = 8, KB = KMAX / NB;
     if (__ballot(x < reg[KMAX - 1]) == 0ull) return;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
