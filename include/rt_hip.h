@@ -397,6 +397,22 @@ int rt_photon_irradiance_dev(rt_scene* s, int which, const float* d_pos3,
                              const float* d_nrm3, int64_t q, int k, float maxDist,
                              float* d_rgb, void* hip_stream);
 
+/* rt_photon_irradiance_dev for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernels,
+ * same bits; the per-call workspace (the query sort's keys, indices and storage, the list of queries redone by the
+ * strict kernel) is a fixed 16 MiB array inside the library's code object instead of a grow-only allocation of the
+ * scene, and the call issues no hipMalloc / hipFree or any allocating routine.  Limits and rules:
+ *   - at most RT_NOALLOC_MAX_QUERIES queries per call (RT_E_LIMIT beyond; split the call);
+ *   - rt_init() resolves the array's address on every gfx950 device; without it the first call on a device does
+ *     (one hipGetSymbolAddress), so call rt_init before capturing a graph;
+ *   - every GPU has ONE such array, shared by all scenes and streams on it: calls that overlap in time on one GPU
+ *     race on it (issue them on one stream, or order them with events).  The array keeps the last call's contents;
+ *     the call clears what must start at zero on its stream.                                                     */
+#define RT_NOALLOC_MAX_QUERIES 262144
+int rt_photon_irradiance_noalloc_dev(rt_scene* s, int which, const float* d_pos3,
+                                     const float* d_nrm3, int64_t q, int k, float maxDist,
+                                     float* d_rgb, void* hip_stream);
+
 /* ---- frame --------------------------------------------------------------- */
 
 /* Replaces GenerateColorImage (hw4.cpp:1081-1129, up to the quantised image)

@@ -21,6 +21,8 @@ RT_OPT_KNN, RT_KNN_STRICT, RT_KNN_FAST = 2, 0, 1
 RT_OPT_LANE_DEPTH = 3
 RT_OPT_KNN_STATS = 4
 RT_OPT_FUSED_PRIMARY = 5
+RT_NOALLOC_MAX_QUERIES = 262144
+RT_E_INVALID, RT_E_NODEVICE, RT_E_NOMEM, RT_E_LIMIT, RT_E_STATE, RT_E_HIP = -1, -2, -3, -4, -5, -6
 
 _f, _i32, _i64, _u8 = C.c_float, C.c_int32, C.c_int64, C.c_uint8
 
@@ -91,6 +93,7 @@ SYMBOLS = [
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit", "rt_photonmap_emit_dev",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_knn_set", "rt_photon_irradiance", "rt_photon_irradiance_dev",
+    "rt_photon_irradiance_noalloc_dev",
     "rt_render", "rt_render_dev", "rt_render_radiance", "rt_render_pixel_list", "rt_generate_primary_dev",
 ]
 
@@ -154,6 +157,7 @@ def load():
         L.rt_photon_knn_dev.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]
         L.rt_photon_irradiance.argtypes = [vp, i32, vp, vp, i64, i32, C.c_float, vp]
         L.rt_photon_irradiance_dev.argtypes = [vp, i32, vp, vp, i64, i32, C.c_float, vp, vp]
+        L.rt_photon_irradiance_noalloc_dev.argtypes = [vp, i32, vp, vp, i64, i32, C.c_float, vp, vp]
     _LIB = L
     return L
 

@@ -126,6 +126,10 @@ int rt_init(int ndev_wanted) {
     for (int d = 0; d < n; ++d) good += is_gfx950(d) ? 1 : 0;
     if (good == 0) return rt_fail(RT_E_NODEVICE, "no gfx950 device among %d HIP devices", n);
     if (ndev_wanted > good) return rt_fail(RT_E_NODEVICE, "%d devices wanted, %d gfx950 visible", ndev_wanted, good);
+    // the fixed workspace of rt_photon_irradiance_noalloc_dev: resolve its address on every usable device now, so that
+    // the entry point itself has nothing to set up (noalloc.hip)
+    for (int d = 0; d < n; ++d)
+        if (is_gfx950(d)) { const int rc = rt_noalloc_setup(d); if (rc) return rc; }
     return good;
 }
 

@@ -50,3 +50,4 @@ struct rt_scene {
 
 int rt_fail(int code, const char* fmt, ...);
 int rt_hipfail(hipError_t e, const char* what);
+int rt_noalloc_setup(int dev);      // noalloc.hip: resolves the fixed workspace of rt_photon_irradiance_noalloc_dev on device `dev`
