@@ -40,6 +40,7 @@ static const double CONE_COS = env_f("RT_BVH_CONE_COS", 0.2);
 
 struct BvhBuilder {
     const rt_scene_desc* d;
+    double dbg_slack = 1.0;             // RT_DEBUG_SLACK_SCALE (tests only), read per build
     std::vector<int32_t> idx;           // triangle (scene prim) ids, partitioned in place
     std::vector<float> gm_of;           // per scene prim: |e1| |e2|
     size_t par_min;
@@ -213,8 +214,10 @@ struct BvhBuilder {
         {   // lateral_slack (trace_device.h) for |dir| in [0.999, 1.001], the rays traverse_bvh takes; 15 eps = 8.9e-7 is
             // applied as 1.0e-6
             const double g = 1.001 * (double)n.gm, d0 = 1e-6 - 4.0e-7 * g;
-            r.slack = d0 > 1e-12 ? (float)std::min(1e30, (1.0e-6 * g / d0) * (1.0 + 1e-6) + 2e-5) : 1e30f;
-            r.cone_k = n.amin > 0.f ? (float)std::min(1e30, (1.0e-6 * g / (0.999 * (double)n.amin)) * (1.0 + 1e-6)) : 1e30f;
+            // dbg_slack: 1 in the product; RT_DEBUG_SLACK_SCALE shrinks the LATERAL part only (the slab-rounding term stays), so
+            // that tests can show which rays need it (tests/test_gpu_trace.py: adversarial grazing rays)
+            r.slack = d0 > 1e-12 ? (float)std::min(1e30, dbg_slack * (1.0e-6 * g / d0) * (1.0 + 1e-6) + 2e-5) : 1e30f;
+            r.cone_k = n.amin > 0.f ? (float)std::min(1e30, dbg_slack * (1.0e-6 * g / (0.999 * (double)n.amin)) * (1.0 + 1e-6)) : 1e30f;
             double dc = 0.0, rad = 0.0;
             for (int k = 0; k < 3; ++k) {
                 const double c = 0.5 * ((double)n.lo[k] + n.hi[k]) - croot[k], h = 0.5 * ((double)n.hi[k] - n.lo[k]);
@@ -274,6 +277,7 @@ int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err) 
             }
     std::sort(refs.begin(), refs.end(), [](const Ref& x, const Ref& y) { return x.prim < y.prim || (x.prim == y.prim && x.rank < y.rank); });
     BvhBuilder B;
+    B.dbg_slack = std::max(0.0, env_f("RT_DEBUG_SLACK_SCALE", 1.0));
     B.d = d;
     std::vector<int32_t> first_of((size_t)d->nprim, -1), count_of((size_t)d->nprim, 0);
     flat->bvh_ref_leaf.resize(refs.size());

@@ -15,6 +15,8 @@
 #include <memory>
 #include <thread>
 
+static float dbg_slack_scale() { const char* e = getenv("RT_DEBUG_SLACK_SCALE"); const double v = e && *e ? atof(e) : 1.0; return (float)(v < 0.0 ? 0.0 : v); }
+
 namespace {
 
 // algebra3 semantics needed on the host (algebra3.cpp:280-282, 295-302, 345-347)
@@ -191,7 +193,9 @@ struct Flattener {
                     nrm[(size_t)nn++] = u; ax[0] += u[0]; ax[1] += u[1]; ax[2] += u[2];
                 }
             }
-            g.gm = gm;
+            // RT_DEBUG_SLACK_SCALE (tests only; 1 in the product) shrinks the lateral inflation of the group boxes, which
+            // lateral_slack (trace_device.h) takes in proportion to gm; the distance-culling margin below keeps the real gm
+            g.gm = gm * dbg_slack_scale();
             const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
             double cmin = 0.0;
             if (al > 1e-12 && nn > 0) {

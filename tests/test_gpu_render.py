@@ -278,3 +278,53 @@ def test_fused_primary_frame_equals_the_wavefront_passes(monkey_sd):
     b, ib, _ = g.render(cam, host.default_params("hw4", primary_only=1), want_ids=True)
     assert np.array_equal(a, b) and np.array_equal(ia, ib) and (ia >= 0).any() and (a != a[0, 0]).any()
     g.close()
+
+
+@pytest.fixture(scope="module")
+def mesh1m():
+    """BASELINE configuration 3's scene at its bench size: 1 000 000 triangles + floor (raytracer_amd/synth.py, the
+    scene of bench.py's mesh_1m / drt_1m lines).  Parity unpinned (no reference scene of this size exists); checker =
+    the oracle.  Materials as the drt_1m line has them (sphere reflect 0.3, floor 0.5)."""
+    from raytracer_amd import synth
+    sd = synth.mesh_scene(1000, 500, reflect=0.3)
+    g = host.Scene(sd); o = ol.OracleScene(sd)
+    yield sd, g, o
+    g.close(); o.close()
+
+
+def test_mesh_1m_primary_and_shadow_frame_vs_oracle(mesh1m):
+    """240x135 subsample of the bench frame, primary + shadow rays (the fused kernel over the build's BVH) and the full
+    Whitted recursion: hit ids bit-exact, frame within 1 LSB on >= 99.5 % of the pixels."""
+    sd, g, o = mesh1m
+    res = (240, 135)
+    cam = host.camera_for(sd, res); ocam = ol.oracle_camera(sd.eye, sd.view, sd.fov, *res)
+    for kw in (dict(primary_only=1), dict()):
+        p = host.default_params("hw4", **kw)
+        for mode in ("bvh", "fast"):
+            g.set_traversal(mode)
+            rgb, ids, st = g.render(cam, p, want_ids=True)
+            orgb, oids, _ = o.render_whitted(ocam, p)
+            assert np.array_equal(ids, oids), (kw, mode, int((ids != oids).sum()))
+            d = np.abs(rgb.astype(int) - orgb.reshape(rgb.shape).astype(int)).max(-1)
+            assert (d > 1).sum() <= 0.005 * res[0] * res[1], (kw, mode)
+            assert (ids >= 2).sum() > 3000 and st.rays_shadow > 0
+    g.set_traversal("bvh")
+
+
+def test_mesh_1m_distributed_ray_tracing_vs_oracle(mesh1m):
+    """the drt_1m bench line's samplers (jitter, thin lens, ball light, glossy lobe; depth <= 10) on the 1 M-triangle scene
+    at 96x54 x 4 spp: sample-0 hit ids bit-exact, radiance within 1e-4 * max(1, |L|) on >= 99.5 % of the pixels.  The
+    passes of recursion depth >= 2 run in the per-lane kernels (RT_OPT_LANE_DEPTH), so those are covered too."""
+    sd, g, o = mesh1m
+    res = (96, 54)
+    kw = dict(spp=4, lens_radius=0.01, focal_distance=1.3, light_radius=0.5, glossy=0.05, seed=3)
+    p = host.default_params("hw4", **kw)
+    cam = host.camera_for(sd, res)
+    rgb, ids, st = g.render(cam, p, want_ids=True)
+    rad, _ = g.render_radiance(cam, p)
+    orgb, oids, orad = o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *res), p, want_radiance=True)
+    assert np.array_equal(ids, oids)
+    orad = orad.reshape(res[1], res[0], 3)
+    bad = (np.abs(rad - orad) > 1e-4 * np.maximum(1.0, np.abs(orad))).any(-1)
+    assert bad.sum() <= 0.005 * res[0] * res[1], (int(bad.sum()), float(np.abs(rad - orad).max()))
+    assert st.rays_reflect > 1000 and st.passes >= 4

@@ -123,11 +123,11 @@ def test_final_scene_brute_force_with_spheres_and_culling():
     g.close(); o.close()
 
 
-def _soup_scene(n, seed, nobj=3, big_floor=True):
+def _soup_scene(n, seed, nobj=3, big_floor=True, spread=0.45, tri=0.03):
     """random triangle soup in several objects, plus two large floor triangles (large |e1||e2| slack)."""
     from raytracer_amd.scene import SceneData
     rng = np.random.default_rng(seed)
-    c = rng.uniform(-0.45, 0.45, (n, 1, 3)); v = (c + rng.normal(scale=0.03, size=(n, 3, 3))).astype(np.float32)
+    c = rng.uniform(-spread, spread, (n, 1, 3)); v = (c + rng.normal(scale=tri, size=(n, 3, 3))).astype(np.float32)
     v[..., 2] += 0.6
     if big_floor:
         v[0] = [[-2, -0.5, -1], [-2, -0.5, 3], [2, -0.5, 3]]; v[1] = [[-2, -0.5, -1], [2, -0.5, 3], [2, -0.5, -1]]
@@ -201,6 +201,41 @@ def _grazing_rays(sd, n, seed):
     return np.concatenate([o, d], axis=1).astype(np.float32)
 
 
+def _adversarial_rays(sd, n, seed, first_tri=0):
+    """Rays built to need the culling slack, not merely to graze: for a triangle, the vertex V that is extreme
+    along a coordinate axis a (so V defines a face of the triangle's bounding box), a plane point p just BEYOND V along a
+    (10^-4 .. 5 % of the triangle's size outside), and a direction d that lies in the triangle's plane at right angles to a,
+    tilted out of the plane by exactly so much that |det| = |d . (e1 x e2)| falls in [1.05e-6, 4e-6] -- just above the
+    reference's cut-off (hw4.cpp:209), where 1/det amplifies the rounding of u, v by up to 10^6 and the reference accepts
+    plane points outside the triangle.  The whole ray stays outside the triangle's box along a, so a traversal that
+    inflates its boxes by less than the reference's rounding can reach skips a hit the reference finds.  Solved in
+    float64, rounded to float32 at the end."""
+    rng = np.random.default_rng(seed)
+    tri = sd.prims[first_tri:, :9].reshape(-1, 3, 3).astype(np.float64)
+    e1a, e2a = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    ok = np.linalg.norm(np.cross(e1a, e2a), axis=1) > 2e-5            # a tilt <= 0.2 rad must reach |det| = 4e-6
+    tri = tri[ok]
+    t = tri[rng.integers(0, tri.shape[0], n)]
+    k = np.arange(n)
+    ax = rng.integers(0, 3, n); sg = rng.choice([-1.0, 1.0], n)
+    a = np.zeros((n, 3)); a[k, ax] = sg
+    V = t[k, (t[k, :, ax] * sg[:, None]).argmax(1)]
+    e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+    N = np.cross(e1, e2); area2 = np.linalg.norm(N, axis=1, keepdims=True); nrm = N / area2
+    out = a - (a * nrm).sum(1, keepdims=True) * nrm                   # a projected into the plane: points out of the box
+    lo = np.linalg.norm(out, axis=1, keepdims=True)
+    w = np.cross(nrm, a); lw = np.linalg.norm(w, axis=1, keepdims=True)
+    good = (lo[:, 0] > 0.2) & (lw[:, 0] > 0.2)                        # planes (almost) at right angles to a have no such direction
+    out /= np.maximum(lo, 1e-30); w /= np.maximum(lw, 1e-30)
+    size = np.sqrt(area2)
+    p = V + (10.0 ** rng.uniform(-4, -1.3, (n, 1))) * size * out + rng.uniform(-0.3, 0.3, (n, 1)) * size * w
+    tilt = rng.uniform(1.05e-6, 4e-6, (n, 1)) / area2 * rng.choice([-1.0, 1.0], (n, 1))
+    d = w + tilt * nrm
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = p - (10.0 ** rng.uniform(-0.3, 1.3, (n, 1))) * d
+    return np.concatenate([o, d], axis=1).astype(np.float32)[good]
+
+
 @pytest.mark.parametrize("which", ["monkey", "soup"])
 def test_grazing_rays_agree_across_traversals(which, monkey_sd):
     """1.5 M rays a fraction of a degree off a triangle's plane, from 0.1 to 30 units away: every traversal returns the
@@ -220,6 +255,100 @@ def test_grazing_rays_agree_across_traversals(which, monkey_sd):
         _assert_hits_equal(g.trace_closest(rays), want)
         assert np.array_equal(g.trace_any(rays), want_any), mode
     g.close()
+
+
+def _adversarial_scene(which, monkey_sd):
+    if which == "monkey":
+        return monkey_sd, 2                                            # the floor's two triangles are an object of their own
+    if which == "soup":
+        return _soup_scene(3000, 31), 2
+    # triangles of ~0.3 units in a 4-unit box, seen from up to 20 units away: |e1||e2| / |det| is large enough that the
+    # reference accepts plane points a few % of a triangle outside it -- far more than the slab-rounding term covers
+    return _soup_scene(600, 9, nobj=2, big_floor=False, spread=2.0, tri=0.3), 0
+
+
+@pytest.mark.parametrize("which", ["monkey", "soup", "coarse"])
+def test_adversarial_grazing_rays_agree_across_traversals(which, monkey_sd):
+    """1 M rays built so that |det| lies in [1.05e-6, 4e-6] and the true plane point lies just beyond a box-defining vertex
+    of the triangle (_adversarial_rays): every culled traversal must still return the strict one's hit (= the reference's
+    loop; the oracle is asked on a sample), bit for bit."""
+    sd, first = _adversarial_scene(which, monkey_sd)
+    rays = _adversarial_rays(sd, 1_000_000, 5, first_tri=first)
+    g = host.Scene(sd); g.set_traversal("strict")
+    want = g.trace_closest(rays); want_any = g.trace_any(rays)
+    assert (want["prim"] >= 0).sum() > 500_000
+    o = ol.OracleScene(sd)
+    sel = np.arange(0, rays.shape[0], 61)
+    _assert_hits_equal(want[sel], o.trace_closest(rays[sel]))
+    o.close()
+    for mode in ("fast", "lane", "bvh"):
+        g.set_traversal(mode)
+        _assert_hits_equal(g.trace_closest(rays), want)
+        assert np.array_equal(g.trace_any(rays), want_any), mode
+    g.close()
+
+
+def test_adversarial_rays_have_teeth(monkey_sd, monkeypatch):
+    """The same rays against a library whose LATERAL box inflation is switched off (RT_DEBUG_SLACK_SCALE=0, read when a
+    scene is built; the slab-rounding term stays): now the culled traversals lose hits the reference finds -- more than a
+    thousand on the coarse soup, some on monkey -- so the test above does exercise the slack of DESIGN 4.1e rather than
+    pass by luck.  (Measured on MI355X: coarse 1 888 closest-hit / 741 any-hit mismatches per million rays in bvh mode,
+    monkey 145 / 89; with the slack at a tenth, none: the bound is the analysis', not the campaign's.)"""
+    counts = {}
+    for which in ("coarse", "monkey"):
+        sd, first = _adversarial_scene(which, monkey_sd)
+        rays = _adversarial_rays(sd, 1_000_000, 5, first_tri=first)
+        monkeypatch.delenv("RT_DEBUG_SLACK_SCALE", raising=False)
+        g = host.Scene(sd); g.set_traversal("strict")
+        want = g.trace_closest(rays); want_any = g.trace_any(rays)
+        g.close()
+        monkeypatch.setenv("RT_DEBUG_SLACK_SCALE", "0")
+        g = host.Scene(sd)
+        for mode in ("bvh", "fast", "lane"):
+            g.set_traversal(mode)
+            got = g.trace_closest(rays)
+            counts[which, mode] = (int(((got["prim"] != want["prim"]) | (got["len"].view(np.uint32) != want["len"].view(np.uint32))).sum()),
+                                   int((g.trace_any(rays) != want_any).sum()))
+        g.close()
+        monkeypatch.delenv("RT_DEBUG_SLACK_SCALE")
+    print("mismatches without the lateral slack:", counts)
+    assert counts["coarse", "bvh"][0] >= 1000 and counts["coarse", "lane"][0] >= 1000 and counts["coarse", "fast"][0] >= 100
+    assert counts["coarse", "bvh"][1] >= 200
+    assert counts["monkey", "bvh"][0] >= 20
+
+
+@pytest.fixture(scope="module")
+def mesh100k():
+    """BASELINE configuration 3's generator (raytracer_amd/synth.py) at 102 400 triangles + floor.  No reference scene
+    has this many triangles ("parity unpinned": the checker is the oracle, whose KD builder and traversal are pinned on
+    monkey and on random soups against the reference)."""
+    from raytracer_amd import synth
+    sd = synth.mesh_scene(320, 160)
+    g = host.Scene(sd); o = ol.OracleScene(sd)
+    yield sd, g, o
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict", "lane", "bvh"])
+def test_synthetic_mesh_100k_vs_oracle(mesh100k, mode):
+    sd, g, o = mesh100k
+    g.set_traversal(mode)
+    gi, oi = g.info(), o.info()
+    assert (gi.kd_nodes_built, gi.kd_max_depth, gi.flat_nodes, gi.leaf_refs) == (oi.kd_nodes_built, oi.kd_max_depth, oi.flat_nodes, oi.leaf_refs)
+    rays = np.concatenate([_primary_rays(sd, 320, 180), _random_rays(20000, 71, box=0.8), _edge_rays()])
+    want = o.trace_closest(rays)
+    assert (want["prim"] >= 2).sum() > 10_000
+    _assert_hits_equal(g.trace_closest(rays), want)
+    # shadow rays of the primary hits towards the light + the random rays, both any-hit semantics
+    ok = want["prim"] >= 0
+    pts = want["p"][ok][:40000]
+    light = np.array(sd.lights[0]["pos"], np.float32)
+    d = light - pts; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    srays = np.concatenate([np.concatenate([pts + np.float32(1e-4) * d, d], axis=1).astype(np.float32), rays[-20000:]])
+    oo = o.trace_any(srays)
+    assert 0 < oo.sum() < oo.size and np.array_equal(g.trace_any(srays), oo)
+    tmax = np.random.default_rng(6).uniform(0.02, 1.5, srays.shape[0]).astype(np.float32)
+    assert np.array_equal(g.trace_any(srays, tmax), o.trace_any(srays, tmax))
 
 
 @pytest.mark.parametrize("mode", ["fast", "strict", "lane", "bvh"])
