@@ -15,12 +15,23 @@
  *   - nothing here throws, exits or falls back to a CPU path: if no gfx950
  *     device is usable the calls fail with RT_E_NODEVICE;
  *   - "host" entry points take caller-owned host buffers (pageable is fine,
- *     the library stages them); "_dev" entry points take device pointers that
- *     live on the scene's GPU and run on the caller's HIP stream without any
- *     host synchronisation;
- *   - one host thread per rt_scene at a time (the reference is single-threaded
- *     with global state, hw4.cpp:49-66); different scenes may be used from
- *     different threads.
+ *     the library stages them) and are synchronous; "_dev" entry points take
+ *     device pointers that live on the scene's GPU and enqueue their work on
+ *     the caller's HIP stream.  These return WITHOUT host synchronisation:
+ *     rt_trace_closest_dev, rt_trace_any_dev, rt_generate_primary_dev,
+ *     rt_photon_knn_dev, rt_photon_irradiance_dev / _noalloc_dev, and
+ *     rt_render_dev for the primary + shadow frame (rt_params.primary_only, one
+ *     sample, no rt_stats).  These synchronise the stream: rt_trace_work_dev
+ *     and rt_photonmap_emit_dev (they return counts), rt_render_dev with
+ *     rt_stats, and rt_render_dev with recursion (once per depth, to size the
+ *     next pass by the number of child rays; a frame is 10-100 ms of device
+ *     time by then).  The first call of a size also grows the scene's scratch
+ *     (hipMalloc; hipFree of the smaller block after a stream synchronise);
+ *   - one host thread AND one stream per rt_scene at a time: the scene's
+ *     scratch blocks are shared by its calls, so two calls on the same scene
+ *     must be ordered on one stream (or by events).  The reference is
+ *     single-threaded with global state (hw4.cpp:49-66); different scenes may
+ *     be used from different threads and streams.
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -31,7 +42,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* error codes */
 #define RT_OK            0
@@ -196,6 +207,15 @@ typedef struct rt_stats {
     int64_t trace_closest_launches, trace_any_launches;
     int64_t closest_work[4];    /* rt_trace_work_dev's four counters over all closest-hit passes (count_work) */
     int64_t any_work[4];        /* the same over all any-hit passes                                          */
+    /* appended with RT_ABI_VERSION 2 (measurement only) */
+    double  knn_ms;             /* RT_RENDER_PHOTON: device time of all radiance-estimate launches (query sort, k_irr_main,
+                                   strict redo), HIP events on the call's stream                              */
+    int64_t knn_launches;
+    double  lane_closest_ms;    /* the part of trace_closest_ms spent in per-lane passes (recursion depth >= RT_OPT_LANE_DEPTH) */
+    double  lane_any_ms;        /* the same of trace_any_ms                                                  */
+    int64_t lane_closest_launches, lane_any_launches;
+    int64_t lane_closest_rays, lane_any_rays;   /* queue entries traced by those passes (inactive slots included) */
+    int64_t lane_closest_work[4], lane_any_work[4];   /* count_work: the part of closest_work / any_work of those passes */
 } rt_stats;
 
 /* 40-byte photon record, field order of PhotonStruct photon.h:133-141.          */
@@ -342,6 +362,17 @@ int rt_photonmap_upload(rt_scene* s, int which, const rt_photon* heap_order, int
 int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, float power_scale);
 /* power_scale: ScalePhotonPower(power_scale, 0, n) after the balance as final.cpp:1126 does it, i.e.
  * heap slots 0..n-1 are scaled and slot n keeps its power (photon.cpp:826-833); 1.0f = leave.   */
+
+/* One build per node (no counterpart: the reference is one process).  With the map replicated on every GPU, one rank
+ * balances and uploads (rt_photonmap_build) and the others copy its DEVICE IMAGE -- both heaps and the sub-heap boxes as
+ * the kernels read them -- instead of repeating the host build: rt_photonmap_image_bytes gives its size, rt_photonmap_export_dev
+ * copies it into a caller's device buffer (what the rank hands to the RCCL broadcast) together with the photons'
+ * bounding box, rt_photonmap_import_dev installs a received image.  export enqueues on the stream; import returns when
+ * the copy is done.  raytracer_amd/dist.py: build_photon_maps.                                                       */
+int rt_photonmap_image_bytes(rt_scene* s, int which, int64_t* nphotons, int64_t* bytes);
+int rt_photonmap_export_dev(rt_scene* s, int which, void* d_dst, int64_t cap_bytes, float box6[6], void* hip_stream);
+int rt_photonmap_import_dev(rt_scene* s, int which, const void* d_src, int64_t nphotons, int64_t bytes,
+                            const float box6[6], void* hip_stream);
 
 /* Parameters of one emission loop of PhotonMappingImageSynthesis (final.cpp:1053-1123).           */
 typedef struct rt_emit_params {

@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_PRIM_TRIANGLE, RT_PRIM_SPHERE, RT_PRIM_DISABLED = 0, 1, 255
 RT_LIGHT_POINT, RT_LIGHT_RECT = 0, 1
 RT_SCENE_CULLING, RT_SCENE_KD_REFERENCE = 1, 2
@@ -75,7 +75,10 @@ class rt_stats(C.Structure):
                 ("rays_gather", _i64), ("knn_lookups", _i64), ("passes", _i64), ("kernel_ms", C.c_double),
                 ("trace_closest_ms", C.c_double), ("trace_any_ms", C.c_double),
                 ("trace_closest_launches", _i64), ("trace_any_launches", _i64),
-                ("closest_work", _i64 * 4), ("any_work", _i64 * 4)]
+                ("closest_work", _i64 * 4), ("any_work", _i64 * 4),
+                ("knn_ms", C.c_double), ("knn_launches", _i64), ("lane_closest_ms", C.c_double), ("lane_any_ms", C.c_double),
+                ("lane_closest_launches", _i64), ("lane_any_launches", _i64), ("lane_closest_rays", _i64),
+                ("lane_any_rays", _i64), ("lane_closest_work", _i64 * 4), ("lane_any_work", _i64 * 4)]
 
 
 # numpy views of the POD records
@@ -92,6 +95,7 @@ SYMBOLS = [
     "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
     "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit", "rt_photonmap_emit_dev",
+    "rt_photonmap_image_bytes", "rt_photonmap_export_dev", "rt_photonmap_import_dev",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_knn_set", "rt_photon_irradiance", "rt_photon_irradiance_dev",
     "rt_photon_irradiance_noalloc_dev",
     "rt_render", "rt_render_dev", "rt_render_radiance", "rt_render_pixel_list", "rt_generate_primary_dev",
@@ -152,6 +156,9 @@ def load():
         L.rt_photonmap_build.argtypes = [vp, i32, vp, i64, C.c_float]
         L.rt_photonmap_emit.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64)]
         L.rt_photonmap_emit_dev.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64), vp]
+        L.rt_photonmap_image_bytes.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]
+        L.rt_photonmap_export_dev.argtypes = [vp, i32, vp, i64, vp, vp]
+        L.rt_photonmap_import_dev.argtypes = [vp, i32, vp, i64, i64, vp, vp]
         L.rt_photon_knn.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp]
         L.rt_photon_knn_set.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp]
         L.rt_photon_knn_dev.argtypes = [vp, i32, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]

@@ -217,8 +217,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (const char* e = getenv("RT_LANE_LAYOUT_MASK")) v.lane_layout_mask = atoi(e) & 7;
     if (!rc) {
         void* q = nullptr;
-        if (hipMalloc(&q, 64) != hipSuccess) rc = rt_fail(RT_E_NOMEM, "hipMalloc failed");
-        else { s->allocs.push_back(q); v.ray_counter = (uint32_t*)q; }
+        if (hipMalloc(&q, 64 * RT_RAY_COUNTERS) != hipSuccess) rc = rt_fail(RT_E_NOMEM, "hipMalloc failed");
+        else { s->allocs.push_back(q); v.ray_counter = (unsigned long long*)q; }
     }
     if (!rc) rc = upload(s, flat.bvh_tris, &v.bvh_tris);
     if (!rc) rc = upload(s, flat.bvh_tri_ref, &v.bvh_tri_ref);

@@ -20,6 +20,7 @@
 // operations in the reference's order on the nodes the reference would visit.
 //
 // Compile with -ffp-contract=off and correctly rounded f32 divide / sqrt.
+#include <atomic>
 #include <cstdlib>
 #include "trace_device.h"
 #include "rng_device.h"
@@ -122,8 +123,8 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
         const unsigned long long need = __ballot(!have && more);
         if (need != 0ull) {
             const int first = __builtin_ctzll(need);
-            uint32_t base = 0;
-            if (lane == first) base = atomicAdd(sc.ray_counter, (uint32_t)__builtin_popcountll(need));
+            unsigned long long base = 0;
+            if (lane == first) base = atomicAdd(sc.ray_counter, (unsigned long long)__builtin_popcountll(need));
             base = __shfl(base, first, 64);
             if (!have && more) {
                 const int64_t my = (int64_t)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
@@ -338,6 +339,12 @@ static inline int bvh_lanes_usable(const DevSceneView& sc) {
     return (on && sc.nbvh > 0 && sc.ray_counter != nullptr) ? 1 : 0;
 }
 // waves of a refilling kernel: enough to fill the chip several times over, never more than the rays need
+// the launch's own claim counter: the next word of the scene's ring, zeroed on the launch's stream
+static inline hipError_t next_ray_counter(DevSceneView& sc, hipStream_t st) {
+    static std::atomic<unsigned> seq{0};
+    sc.ray_counter = sc.ray_counter + 8 * (size_t)(seq.fetch_add(1) % RT_RAY_COUNTERS);
+    return hipMemsetAsync(sc.ray_counter, 0, sizeof(unsigned long long), st);
+}
 static inline unsigned lanes_grid(int64_t n) {
     static const int64_t cap = [] { const char* e = getenv("RT_LANE_WAVES"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)8192; }();
     const int64_t w = (n + 63) / 64;
@@ -354,9 +361,10 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
     if (fast == 2) {
         const int lanes = bvh_lanes_usable(sc);
         if (lanes) {
-            hipError_t e = hipMemsetAsync(sc.ray_counter, 0, sizeof(uint32_t), st);
+            DevSceneView scl = sc;
+            hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
+            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out);
         }
         hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, lanes, d_out);
         return hipGetLastError();
@@ -375,9 +383,10 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
     if (fast == 2) {
         const int lanes = bvh_lanes_usable(sc);
         if (lanes) {
-            hipError_t e = hipMemsetAsync(sc.ray_counter, 0, sizeof(uint32_t), st);
+            DevSceneView scl = sc;
+            hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ);
         }
         hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, lanes, d_occ);
         return hipGetLastError();

@@ -120,6 +120,48 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, fl
     return upload_heap(s, which, photons, n);
 }
 
+// ---- one build per node: the device image of a map, copied between ranks' GPUs ---------------------------------------
+static size_t image_records(int64_t n) { return 4 * ((size_t)n + 1) + 1 + 2 * ((size_t)n / 2 + 2); }      // as upload_heap lays it out
+
+int rt_photonmap_image_bytes(rt_scene* s, int which, int64_t* nphotons, int64_t* bytes) {
+    if (!s || which < 0 || which > 1 || !nphotons || !bytes) return rt_fail(RT_E_INVALID, "rt_photonmap_image_bytes: bad argument");
+    const PhotonMapDev& m = s->pmap[which];
+    *nphotons = m.d_photons ? m.n : 0;
+    *bytes = m.d_photons ? (int64_t)(image_records(m.n) * sizeof(DevPhotonPos)) : 0;
+    return RT_OK;
+}
+
+int rt_photonmap_export_dev(rt_scene* s, int which, void* d_dst, int64_t cap_bytes, float box6[6], void* stream) {
+    if (!s || which < 0 || which > 1 || !d_dst || !box6) return rt_fail(RT_E_INVALID, "rt_photonmap_export_dev: bad argument");
+    const PhotonMapDev& m = s->pmap[which];
+    if (!m.d_photons) return rt_fail(RT_E_STATE, "rt_photonmap_export_dev: photon map %d not uploaded", which);
+    const size_t bytes = image_records(m.n) * sizeof(DevPhotonPos);
+    if ((int64_t)bytes > cap_bytes) return rt_fail(RT_E_INVALID, "rt_photonmap_export_dev: %zu B do not fit %lld", bytes, (long long)cap_bytes);
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    HIPCHK(hipMemcpyAsync(d_dst, m.d_photons, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "copy photon map image");
+    memcpy(box6, m.box, sizeof m.box);
+    return RT_OK;
+}
+
+int rt_photonmap_import_dev(rt_scene* s, int which, const void* d_src, int64_t nphotons, int64_t bytes, const float box6[6], void* stream) {
+    if (!s || which < 0 || which > 1 || !d_src || !box6 || nphotons < 0) return rt_fail(RT_E_INVALID, "rt_photonmap_import_dev: bad argument");
+    if (nphotons >= ((int64_t)1 << 31) - 2) return rt_fail(RT_E_LIMIT, "rt_photonmap_import_dev: more than 2^31 photons");
+    if ((int64_t)(image_records(nphotons) * sizeof(DevPhotonPos)) != bytes)
+        return rt_fail(RT_E_INVALID, "rt_photonmap_import_dev: %lld B is not the image of %lld photons", (long long)bytes, (long long)nphotons);
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    PhotonMapDev& m = s->pmap[which];
+    if (m.d_photons) { (void)hipFree(m.d_photons); m.d_photons = nullptr; m.n = 0; }
+    hipError_t e = hipMalloc((void**)&m.d_photons, (size_t)bytes);
+    if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(photon map %lld B): %s", (long long)bytes, hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(m.d_photons, d_src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "copy photon map image");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream), "sync");             // the caller may free d_src when this returns
+    m.n = nphotons; m.half = nphotons / 2 - 1;
+    memcpy(m.box, box6, sizeof m.box);
+    return ensure_tables(s);
+}
+
 int rt_host_photon_balance(rt_photon* photons, int64_t n) {
     if (!photons || n < 0) return rt_fail(RT_E_INVALID, "rt_host_photon_balance: bad argument");
     try { rt_photon_balance_host(photons, n); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }

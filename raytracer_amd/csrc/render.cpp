@@ -102,21 +102,25 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     uint32_t* d_total = (uint32_t*)(d_ctr + 8);
     HIPCHK(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long) + 16, st), "memset counters");
 
-    unsigned long long* d_work = nullptr;       // [0..3] closest, [4..7] any (count_work)
+    unsigned long long* d_work = nullptr;       // count_work: [0..3] closest, [4..7] any of the wave-synchronous passes, [8..15] the same of the per-lane passes
     if (stats && p->count_work) {
-        void* w; RTCHK(s->scratch(S_WORK, 8 * sizeof(unsigned long long), &w));
-        HIPCHK(hipMemsetAsync(w, 0, 8 * sizeof(unsigned long long), st), "memset work counters");
+        void* w; RTCHK(s->scratch(S_WORK, 16 * sizeof(unsigned long long), &w));
+        HIPCHK(hipMemsetAsync(w, 0, 16 * sizeof(unsigned long long), st), "memset work counters");
         d_work = (unsigned long long*)w;
     }
 
+    EventBag bag;                     // every event of this call; destroyed on every return path
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;      // per-kernel event pairs: [closest begin, closest end, any begin, any end] per pass
+    std::vector<char> pass_lane;      // per pass: traced by the per-lane kernels
     auto mark = [&](void) -> int {
         if (!stats) return RT_OK;
-        hipEvent_t e; HIPCHK(hipEventCreate(&e), "event"); HIPCHK(hipEventRecord(e, st), "event"); kev.push_back(e);
+        hipError_t err; hipEvent_t e = bag.mark(st, &err);
+        if (!e) return rt_hipfail(err, "event");
+        kev.push_back(e);
         return RT_OK;
     };
-    if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
+    if (stats) { hipError_t err; ev0 = bag.mark(st, &err); if (!ev0) return rt_hipfail(err, "event"); }
 
     // BASELINE configuration 2 (primary + shadow rays, one centre sample) has a kernel of its own
     const bool fused = s->fused_primary && p->primary_only && !drt && (s->fast == 1 || s->fast == 3) && !(stats && p->count_work) &&
@@ -137,7 +141,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         const int64_t nblocks = ctiles;                       // one pair of counts per wave, if the caller wants rt_stats
         void* pairs = nullptr;
         if (stats) RTCHK(s->scratch(S_PAIRS, (size_t)nblocks * 8 + 16, &pairs));
-        ++passes; pass_n.push_back(n0);
+        ++passes; pass_n.push_back(n0); pass_lane.push_back(0);
         RTCHK(mark());
         HIPCHK(rtk_primary_only(s->view, *cam, c_tiles, ctiles, s->eps_f, p->ambient_intensity, p->background, d_rgb8, d_hit_ids,
                                 s->d_radiance_out, (unsigned int*)pairs, s->fast == 3 ? 1 : 0, p->packed_output ? tile0 * 64 : -1, st),
@@ -164,9 +168,9 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const int32_t* q_pix = (const int32_t*)pix0;
     const float* q_nr = nullptr;         // NULL = start_nr ... handled below
     int64_t n = n0;
-    std::vector<float> nrfill;
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
-        ++passes; pass_n.push_back(n);
+        const int pass_mode = ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast;   // RT_OPT_LANE_DEPTH
+        ++passes; pass_n.push_back(n); pass_lane.push_back(pass_mode == 2 ? 1 : 0);
         const bool spawn = !p->primary_only && depth < p->max_depth;
         void *hits, *srays, *sact, *occ, *contrib, *flags = nullptr, *bsums = nullptr, *pairs;
         RTCHK(s->scratch(S_PAIRS, (size_t)((n + 255) / 256) * 8 + 16, &pairs));
@@ -180,20 +184,21 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
         }
         RTCHK(mark());
-        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast, (rt_hit*)hits, st), "k_trace_closest");
+        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st), "k_trace_closest");
         RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
                                (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, q_code, p->seed, p->light_radius, st), "k_shade_flags");
         RTCHK(mark());
         if (L > 0)
-            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast, (uint8_t*)occ, st), "k_trace_any");
+            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, st), "k_trace_any");
         RTCHK(mark());
         if (d_work) {
-            HIPCHK(rtk_trace_work(s->view, q_rays, q_pix, nullptr, n, s->eps_f, s->fast, 0, d_work, st), "k_trace_work");
+            unsigned long long* dw = d_work + (pass_mode == 2 ? 8 : 0);
+            HIPCHK(rtk_trace_work(s->view, q_rays, q_pix, nullptr, n, s->eps_f, s->fast, 0, dw, st), "k_trace_work");
             if (L > 0)
                 HIPCHK(rtk_trace_work(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, s->fast, 1,
-                                      d_work + 4, st), "k_trace_work");
+                                      dw + 4, st), "k_trace_work");
         }
         HIPCHK(rtk_shade_lights(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, n, (const uint8_t*)occ,
                                 p->ambient_intensity, cam->center, (float*)contrib, d_ctr, st), "k_shade_lights");
@@ -210,8 +215,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         if (!nr_in && p->start_nr != 1.0f) {
             // first pass with a start index other than 1: materialise it (k_spawn treats NULL as 1.0)
             void* tmp; RTCHK(s->scratch(toA ? S_QB_NR : S_QA_NR, (size_t)n * 4, &tmp));
-            nrfill.assign((size_t)n, p->start_nr);
-            HIPCHK(hipMemcpyAsync(tmp, nrfill.data(), (size_t)n * 4, hipMemcpyHostToDevice, st), "copy nr");
+            int nr_bits; memcpy(&nr_bits, &p->start_nr, 4);
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)tmp, nr_bits, (size_t)n, st), "fill nr");      // on the device: no pageable host copy
             nr_in = (const float*)tmp;
         }
         void* ocode = nullptr;
@@ -231,31 +236,37 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     if (s->d_radiance_out) HIPCHK(rtk_copy_radiance(pixlist, nslots, (const float*)accum, s->d_radiance_out, st), "k_copy_radiance");
     }   // chunks
     if (stats) {
-        HIPCHK(hipEventRecord(ev1, st), "event");
-        unsigned long long h[8], hw[8] = {};
+        { hipError_t err; ev1 = bag.mark(st, &err); if (!ev1) return rt_hipfail(err, "event"); }
+        unsigned long long h[8], hw[16] = {};
         HIPCHK(hipMemcpyAsync(h, d_ctr, sizeof h, hipMemcpyDeviceToHost, st), "read counters");
         if (d_work) HIPCHK(hipMemcpyAsync(hw, d_work, sizeof hw, hipMemcpyDeviceToHost, st), "read work counters");
         HIPCHK(hipStreamSynchronize(st), "sync");
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1), "event time");
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
         memset(stats, 0, sizeof *stats);
         stats->rays_reflect = (int64_t)h[3]; stats->rays_refract = (int64_t)h[4];
         stats->rays_primary = (int64_t)h[0] - stats->rays_reflect - stats->rays_refract;
         stats->rays_shadow = (int64_t)h[1] * L;      // one shadow ray per hit and light (hw4.cpp:929-931)
         stats->passes = passes;
         stats->kernel_ms = ms;
-        for (int c = 0; c < 4; ++c) { stats->closest_work[c] = (int64_t)hw[c]; stats->any_work[c] = (int64_t)hw[4 + c]; }
+        for (int c = 0; c < 4; ++c) {
+            stats->closest_work[c] = (int64_t)(hw[c] + hw[8 + c]); stats->any_work[c] = (int64_t)(hw[4 + c] + hw[12 + c]);
+            stats->lane_closest_work[c] = (int64_t)hw[8 + c]; stats->lane_any_work[c] = (int64_t)hw[12 + c];
+        }
         for (size_t i = 0; i + 3 < kev.size(); i += 4) {
             float a = 0.f, b = 0.f;
             HIPCHK(hipEventElapsedTime(&a, kev[i], kev[i + 1]), "event time");
             HIPCHK(hipEventElapsedTime(&b, kev[i + 2], kev[i + 3]), "event time");
+            const bool any_launched = L > 0 && !fused;
             stats->trace_closest_ms += a; stats->trace_any_ms += b;
-            stats->trace_closest_launches += 1; stats->trace_any_launches += (L > 0 && !fused) ? 1 : 0;
+            stats->trace_closest_launches += 1; stats->trace_any_launches += any_launched ? 1 : 0;
+            if (pass_lane[i / 4]) {
+                stats->lane_closest_ms += a; stats->lane_closest_launches += 1; stats->lane_closest_rays += pass_n[i / 4];
+                if (any_launched) { stats->lane_any_ms += b; stats->lane_any_launches += 1; stats->lane_any_rays += pass_n[i / 4] * L; }
+            }
             if (getenv("RT_TRACE_PASSES"))
-                fprintf(stderr, "pass %zu: %lld rays, closest %.3f ms, any %.3f ms\n", i / 4, (long long)pass_n[i / 4], a, b);
+                fprintf(stderr, "pass %zu: %lld rays, closest %.3f ms, any %.3f ms%s\n", i / 4, (long long)pass_n[i / 4], a, b, pass_lane[i / 4] ? " (per lane)" : "");
         }
-        for (hipEvent_t e : kev) (void)hipEventDestroy(e);
     }
     return RT_OK;
 }

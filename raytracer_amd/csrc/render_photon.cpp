@@ -36,7 +36,19 @@ struct Arena {   // bump allocator over one scratch slot
     }
 };
 
-int knn(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st) {
+int knn_launch(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st);
+
+// the radiance estimate, bracketed by events when the caller wants rt_stats.knn_ms
+int knn(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st,
+        EventBag* bag, std::vector<hipEvent_t>* kev) {
+    hipError_t err;
+    if (bag) { hipEvent_t e = bag->mark(st, &err); if (!e) return rt_hipfail(err, "event"); kev->push_back(e); }
+    RTCHK(knn_launch(s, which, pos, nrm, q, k, radius, rgb, st));
+    if (bag) { hipEvent_t e = bag->mark(st, &err); if (!e) return rt_hipfail(err, "event"); kev->push_back(e); }
+    return RT_OK;
+}
+
+int knn_launch(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st) {
     const PhotonMapDev& m = s->pmap[which];
     if (!m.d_photons || m.n < 1) { HIPCHK(hipMemsetAsync(rgb, 0, (size_t)q * 12, st), "memset irradiance"); return RT_OK; }
     if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
@@ -82,8 +94,11 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
     uint32_t* d_total = (uint32_t*)(d_ctr + 8);
     HIPCHK(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long) + 16, st), "memset counters");
 
+    EventBag bag;                          // destroyed on every return path
+    std::vector<hipEvent_t> knn_ev;        // begin / end of every radiance-estimate call
+    EventBag* kb = stats ? &bag : nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (stats) { HIPCHK(hipEventCreate(&ev0), "event"); HIPCHK(hipEventCreate(&ev1), "event"); HIPCHK(hipEventRecord(ev0, st), "event"); }
+    if (stats) { hipError_t err; ev0 = bag.mark(st, &err); if (!ev0) return rt_hipfail(err, "event"); }
     int64_t passes = 0;
     const float inv_g = G > 0 ? (float)(1.0 / (double)(float)G) : 0.f;       // vec3 / (float)G, algebra3.cpp:345-347
 
@@ -122,7 +137,7 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
                                 depth == 0 ? d_hit_ids : nullptr, (const int32_t*)pixmap, d_ctr, st), "k_pm_shade");
             HIPCHK(rtk_pm_shadow(s->view, (const rt_hit*)hits, q_sid, (const float*)nrmL, n, S, s->eps_f, s->fast,
                                  (uint8_t*)occ, d_ctr, st), "k_pm_shadow");
-            RTCHK(knn(s, RT_PMAP_CAUSTIC, (const float*)qpos, (const float*)nrm, n, K, p->knn_radius_caustic, (float*)caustic, st));
+            RTCHK(knn(s, RT_PMAP_CAUSTIC, (const float*)qpos, (const float*)nrm, n, K, p->knn_radius_caustic, (float*)caustic, st, kb, &knn_ev));
             HIPCHK(rtk_pm_direct(s->view, (const rt_hit*)hits, q_sid, q_w, (const float*)nrmL, n, S, (const uint8_t*)occ,
                                  (const float*)caustic, cam->center, (float*)contrib, st), "k_pm_direct");
             HIPCHK(rtk_accumulate(q_sid, (const float*)contrib, n, (float*)accum, st), "k_accumulate");
@@ -151,7 +166,7 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
                     HIPCHK(rtk_trace_closest(s->view, gr[cur], gs[cur], gn, s->eps_f, s->fast, ghits, st), "k_trace_closest");
                     HIPCHK(rtk_gi_shade(s->view, gr[cur], ghits, gs[cur], gn, last, p->start_nr, gflags, gqpos, gqnrm, gkd,
                                         d_ctr, st), "k_gi_shade");
-                    RTCHK(knn(s, RT_PMAP_GLOBAL, gqpos, gqnrm, gn, K, p->knn_radius_global, girr, st));
+                    RTCHK(knn(s, RT_PMAP_GLOBAL, gqpos, gqnrm, gn, K, p->knn_radius_global, girr, st, kb, &knn_ev));
                     HIPCHK(rtk_gi_contrib(gs[cur], gw[cur], gkd, girr, gn, inv_g, gcontrib, st), "k_gi_contrib");
                     HIPCHK(rtk_accumulate(gs[cur], gcontrib, gn, (float*)accum, st), "k_accumulate");
                     if (last) break;
@@ -187,14 +202,18 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
                                (const uint8_t*)hitany, p->background, d_rgb8, s->d_radiance_out, st), "k_pm_finalize");
     }
     if (stats) {
-        HIPCHK(hipEventRecord(ev1, st), "event");
+        { hipError_t err; ev1 = bag.mark(st, &err); if (!ev1) return rt_hipfail(err, "event"); }
         unsigned long long h[8];
         HIPCHK(hipMemcpyAsync(h, d_ctr, sizeof h, hipMemcpyDeviceToHost, st), "read counters");
         HIPCHK(hipStreamSynchronize(st), "sync");
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1), "event time");
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
         memset(stats, 0, sizeof *stats);
+        for (size_t i = 0; i + 1 < knn_ev.size(); i += 2) {
+            float a = 0.f;
+            HIPCHK(hipEventElapsedTime(&a, knn_ev[i], knn_ev[i + 1]), "event time");
+            stats->knn_ms += a; stats->knn_launches += 1;
+        }
         stats->rays_primary = (int64_t)h[0]; stats->rays_gather = (int64_t)h[2];
         stats->rays_reflect = (int64_t)h[3]; stats->rays_refract = (int64_t)h[4];
         stats->rays_shadow = (int64_t)h[1] * S;                   // k_pm_shadow: S rays per eye-path hit

@@ -54,6 +54,7 @@ struct DevLeafGroup {       // 64 B
 };
 static_assert(sizeof(DevLeafGroup) == 64, "DevLeafGroup must be 64 bytes");
 
+#define RT_RAY_COUNTERS 64
 #define RT_PF_SKIP_SHADOW 1   // refract > 0.1
 #define RT_PF_SPHERE      2
 
@@ -120,7 +121,9 @@ struct DevSceneView {       // passed by value to kernels
     const DevBvhNode* bvh_oct[8]; int32_t nbvh;
     float bvh_root_centre[3];           // what DevBvhNode::rho is measured from (the root box's centre, rounded)
     float bvh_root_rho;                 // rho of the root node
-    uint32_t* ray_counter;              // next ray of a k_trace_*_bvh_lanes launch (zeroed by the launcher)
+    unsigned long long* ray_counter;    // next ray of a k_trace_*_bvh_lanes launch.  The scene owns a ring of RT_RAY_COUNTERS such
+                                        // words, 64 B apart; every launch takes the next one and zeroes it on its stream, so two
+                                        // launches in flight (other streams, or back to back) never claim from the same word
     int32_t lane_layout_mask;           // per-lane walks use layout (octant & mask): 0 = one layout for all (default), 7 = the ray's own octant
     const DevLeafTri* bvh_tris;         // every tree triangle once; .rank = its index t into bvh_tri_ref
     const int32_t* bvh_tri_ref;         // [t][2]: first, count into bvh_ref_leaf

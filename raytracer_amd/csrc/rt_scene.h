@@ -48,6 +48,21 @@ struct rt_scene {
     int scratch(int slot, size_t bytes, void** p);
 };
 
+// HIP events of one call, destroyed on every way out of it
+struct EventBag {
+    std::vector<hipEvent_t> ev;
+    ~EventBag() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    // a new event recorded on `st`; nullptr (and *err set) on failure
+    hipEvent_t mark(hipStream_t st, hipError_t* err) {
+        hipEvent_t e = nullptr;
+        *err = hipEventCreate(&e);
+        if (*err != hipSuccess) return nullptr;
+        ev.push_back(e);
+        *err = hipEventRecord(e, st);
+        return *err == hipSuccess ? e : nullptr;
+    }
+};
+
 int rt_fail(int code, const char* fmt, ...);
 int rt_hipfail(hipError_t e, const char* what);
 int rt_noalloc_setup(int dev);      // noalloc.hip: resolves the fixed workspace of rt_photon_irradiance_noalloc_dev on device `dev`

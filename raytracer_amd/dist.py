@@ -72,9 +72,50 @@ def gpu_emitter(scene, e, torch, stream=None):
     return emit
 
 
-def build_photon_maps(scene, torch, targets, seed, rank=0, world=1, dist=None, batch=None):
-    """Both maps of PhotonMappingImageSynthesis (final.cpp:1047-1129): sharded emission, all-gather, then every
-    rank balances + scales the identical array and uploads it (rt_photonmap_build).  targets = (global, caustic)."""
+def share_from_rank0(make_fn, rank, world, dist, device, torch, src=0):
+    """One rank builds, everybody holds: rank `src` calls make_fn() -> (uint8 tensor on `device`, list of int64 header
+    words); the header and then the payload are broadcast (RCCL over xGMI on the GPUs, gloo in the CPU tests).
+    Returns (payload tensor, header list) on every rank.  Used for the balanced photon map: the balance
+    (photon.cpp:133-254) is a serial-ish host job of seconds to tens of seconds, so ONE rank per node runs it and the
+    others receive the result instead of every rank repeating it on the same host's cores."""
+    payload, header = make_fn() if rank == src else (None, None)
+    if world == 1:
+        return payload, header
+    nh = torch.tensor([len(header) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(nh, src)
+    h = torch.tensor(header if rank == src else [0] * int(nh.item()), dtype=torch.int64, device=device)
+    dist.broadcast(h, src)
+    nbytes = torch.tensor([payload.numel() if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(nbytes, src)
+    if rank != src:
+        payload = torch.empty(int(nbytes.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(payload, src)
+    return payload, [int(x) for x in h.tolist()]
+
+
+def balance_on_rank0(photons, scale, rank, world, dist, torch, device="cpu"):
+    """photons: photon_dtype[target + 1] as AddPhoton leaves them (slot 0 unused), identical on every rank after the
+    all-gather.  Rank 0 balances (librt_hip's host builder = PhotonMap::balance) and scales (ScalePhotonPower(scale, 0,
+    n): slots 0..n-1, photon.cpp:826-833); every rank returns the same heap-order array.  Host form of the exchange
+    (CPU tests; the GPU path moves the device image instead: build_photon_maps)."""
+    n = photons.shape[0] - 1
+
+    def make():
+        a = np.ascontiguousarray(photons).copy()
+        abi.check(abi.load().rt_host_photon_balance(a.ctypes.data, n))
+        if scale != 1.0:
+            a["power"][:n] = a["power"][:n] * np.float32(scale)
+        return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(device), [n]
+    payload, _ = share_from_rank0(make, rank, world, dist, device, torch)
+    return np.ascontiguousarray(payload.cpu().numpy()).view(abi.photon_dtype).reshape(-1)
+
+
+def build_photon_maps(scene, torch, targets, seed, rank=0, world=1, dist=None, batch=None, every_rank_builds=False):
+    """Both maps of PhotonMappingImageSynthesis (final.cpp:1047-1129): sharded emission, all-gather, then ONE rank
+    balances + scales the array, builds the second heap and uploads (rt_photonmap_build), and broadcasts the map's
+    device image to the other ranks' GPUs (rt_photonmap_export_dev / _import_dev) -- the host build is not repeated
+    per rank on the same host's cores.  `heap` (the host array in heap order) is returned on rank 0 only.
+    every_rank_builds=True keeps the old shape (each rank builds for itself).  targets = (global, caustic)."""
     from . import host
     out = []
     for which, target in ((abi.RT_PMAP_GLOBAL, targets[0]), (abi.RT_PMAP_CAUSTIC, targets[1])):
@@ -84,7 +125,35 @@ def build_photon_maps(scene, torch, targets, seed, rank=0, world=1, dist=None, b
         e = host.final_emit_params(which, seed=seed)
         st = {}
         ph, used = emit_photon_map(gpu_emitter(scene, e, torch), target, rank, world, batch, dist, "cuda", st)
-        a = np.zeros(target + 1, abi.photon_dtype); a[1:] = ph
-        heap = scene.photonmap_build(which, a, power_scale=float(np.float32(1.0) / np.float32(max(target, 1))))   # final.cpp:1126
+        scale = float(np.float32(1.0) / np.float32(max(target, 1)))                                               # final.cpp:1126
+        if world == 1 or every_rank_builds:
+            a = np.zeros(target + 1, abi.photon_dtype); a[1:] = ph
+            heap = scene.photonmap_build(which, a, power_scale=scale)
+            out.append(dict(heap=heap, emissions=used, **st))
+            continue
+        # one build per node: rank 0 balances, builds the second heap and uploads; the others receive its device image
+        import ctypes as C
+        import time
+        L, sp = scene.L, C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        heap = None
+        t0 = time.perf_counter()
+
+        def make():
+            nonlocal heap
+            a = np.zeros(target + 1, abi.photon_dtype); a[1:] = ph
+            heap = scene.photonmap_build(which, a, power_scale=scale)
+            n, nb = C.c_int64(0), C.c_int64(0)
+            abi.check(L.rt_photonmap_image_bytes(scene.h, which, C.byref(n), C.byref(nb)))
+            img = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+            box = (C.c_float * 6)()
+            abi.check(L.rt_photonmap_export_dev(scene.h, which, img.data_ptr(), nb.value, box, sp))
+            torch.cuda.current_stream().synchronize()
+            return img, [n.value] + [int(np.float32(b).view(np.int32)) for b in box]
+        img, hdr = share_from_rank0(make, rank, world, dist, "cuda", torch)
+        if rank != 0:
+            box = (C.c_float * 6)(*[float(np.int32(b).view(np.float32)) for b in hdr[1:7]])
+            abi.check(L.rt_photonmap_import_dev(scene.h, which, img.data_ptr(), hdr[0], img.numel(), box, sp))
+        st["image_bytes"] = int(img.numel()); st["build_and_share_s"] = time.perf_counter() - t0
+        del img
         out.append(dict(heap=heap, emissions=used, **st))
     return out

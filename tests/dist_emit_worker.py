@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as ol                                   # noqa: E402
 from raytracer_amd import abi, host, scene                # noqa: E402
-from raytracer_amd.dist import emit_photon_map            # noqa: E402
+from raytracer_amd.dist import emit_photon_map, balance_on_rank0   # noqa: E402
 
 
 def main():
@@ -38,7 +38,17 @@ def main():
         dist.all_gather(all_d, digest)
         same_everywhere = all(int(d.item()) == int(digest.item()) for d in all_d)
         alone, used1 = emit_photon_map(emit, target, 0, 1, batch * world)
-        results[str(which)] = dict(n=int(got.size), same_everywhere=same_everywhere,
+        # one build per node: rank 0 balances + scales, everybody receives the heap (dist.py: balance_on_rank0)
+        a = np.zeros(target + 1, abi.photon_dtype); a[1:] = got
+        heap = balance_on_rank0(a, 1.0 / target, rank, world, dist, torch)
+        b = np.zeros(target + 1, abi.photon_dtype); b[1:] = alone
+        abi.check(abi.load().rt_host_photon_balance(b.ctypes.data, target))
+        b["power"][:target] = b["power"][:target] * np.float32(1.0 / target)
+        hd = torch.tensor([int(np.frombuffer(heap.tobytes(), np.uint8).astype(np.int64).sum())], dtype=torch.int64)
+        all_h = [torch.zeros_like(hd) for _ in range(world)]
+        dist.all_gather(all_h, hd)
+        heap_ok = all(int(d.item()) == int(hd.item()) for d in all_h) and heap.tobytes() == b.tobytes()
+        results[str(which)] = dict(n=int(got.size), same_everywhere=same_everywhere, heap_shared_equals_own_balance=bool(heap_ok),
                                    equals_single_process=bool(np.array_equal(got.view(np.uint8), alone.view(np.uint8))),
                                    emissions=int(used), allgather_bytes=int(st.get("allgather_bytes", 0)))
     if rank == 0:

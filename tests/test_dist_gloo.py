@@ -58,4 +58,5 @@ def test_sharded_emission_allgather_over_gloo(world):
     for which, target in (("0", 5000), ("1", 300)):
         res = j["results"][which]
         assert res["n"] == target and res["same_everywhere"] and res["equals_single_process"], res
+        assert res["heap_shared_equals_own_balance"], res          # one balance per node, broadcast
         assert res["allgather_bytes"] > 0
