@@ -12,13 +12,18 @@ with N (weak scaling: 3840x2160 pixels per GPU), 64x64 tiles are dealt round-rob
 ranks (no collective in the tracing path) and every step ends with the RCCL gather of the
 ranks' tiles to rank 0, as north_star prescribes.  Rank 0 prints ONE JSON line.
 
-Extra objects on the line: `roofline` (closest-hit kernel: algorithmic bytes / HIP-event
-time, vs 8 TB/s), `cpu_baseline` (the reference binary oracle/_ref/hw4_ref -- or the oracle
-port when it is absent -- on a bounded sample of the same workload, 1 core), `secondary`
-(photon-map kNN lookups/s on a 10 M-photon map, BASELINE configuration 4's shape).
+Extra objects on the line:
+  roofline      the dominant kernel against the limiter its counters support: `bound` is "hbm" when HBM
+                traffic is the largest of the three busy fractions, else "valu_issue" / "scalar_issue"; achieved / peak /
+                frac belong to that bound and frac <= 1 by construction.  Beside them: the SURVEY 8d algorithmic bytes
+                (per lane), the bytes the waves actually fetch (a record once per wave), the PMC HBM traffic.
+  cpu_baseline  the reference binary (oracle/_ref/hw4_ref) on a bounded sample of the same workload, 1 core
+  secondary     mesh_1m, drt_1m (BASELINE configuration 3), knn, photon_frame (configuration 4), each with its own
+                roofline, cpu_baseline and a parity sample checked against the oracle inside this run.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import subprocess
@@ -31,10 +36,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s achievable)
+# MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 achievable); 256 CUs x 4 SIMD-32 at 2.4 GHz, a wave64 vector instruction
+# issues in 2 cycles (constants table: v_fma_f32 2 cyc; 4 only for a wave alone on its SIMD); one scalar unit per CU
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0          # wave-instructions / ns  -> 1228.8 G wave-instructions / s
+SCALAR_PEAK_GINST = 256 * 2.4               # SALU + SMEM + branch instructions, one per cycle and CU -> 614.4 G / s
 BASE_RES = (3840, 2160)
 TILE = 64
 WEAK_FACTORS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+PROFILE_TAG = "r02"
 
 
 def log(*a):
@@ -69,29 +79,98 @@ def rank_pixel_index(resx, resy, rank, nranks, tile=TILE):
     return np.concatenate(out) if out else np.zeros(0, np.int64)
 
 
-def algorithmic_bytes_per_ray(gs, cam, params, sp):
-    """per ray = 32 B ray in + 32 B x box tests + 36 B x triangle tests + 20 B hit out, with the
-    test counts THIS kernel's algorithm performs per ray.  The counts come from one extra, untimed frame
-    rendered with rt_params.count_work = 1: the same traversal code instantiated with per-lane counters
-    (k_trace_work), on exactly the rays of the bench frame.  (The leaf-index term of SURVEY's formula is 0:
-    leaf triangles are stored in leaf order, there is no index indirection.)"""
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline
+
+_COUNTERS = None
+
+
+def counters(workload, kernel):
+    """per-launch counters of `kernel` in `workload` from the committed rocprofv3 passes (tools/prof_all.sh ->
+    tools/prof_counters.py -> profiles/<tag>_counters.json): HBM bytes (PMC, gfx950-corrected), L2 hit rate, SQ instruction
+    counts.  They are properties of the kernel on this workload, not of a run; the time is measured live."""
+    global _COUNTERS
+    if _COUNTERS is None:
+        _COUNTERS = {}
+        for name in (f"{PROFILE_TAG}_counters.json", "traffic_r01.json"):
+            p = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(p):
+                try:
+                    _COUNTERS = json.load(open(p)); _COUNTERS["_source"] = "profiles/" + name
+                    break
+                except Exception:
+                    pass
+    w = _COUNTERS.get(workload, {})
+    for k, v in w.items():
+        if k == kernel or k.startswith(kernel + "<"):
+            return v, _COUNTERS.get("_source")
+    return None, _COUNTERS.get("_source")
+
+
+def make_roofline(workload, kernel, avg_ms, units_per_launch, alg_bytes, wave_bytes=None, **detail):
+    """The dominant kernel against the three limiters the counters can speak for.
+      hbm      useful HBM bytes / time / 8 TB/s, useful = min(algorithmic bytes, PMC traffic): what the algorithm needs
+               out of what was moved (traffic above the algorithmic bytes is waste, algorithmic bytes above the traffic
+               were served by the scalar cache / L2 and never were HBM's to deliver)
+      valu     vector wave-instructions / time / (1024 SIMDs x 2.4 GHz / 2 cycles)
+      scalar   SALU + SMEM + branch instructions / time / (256 CUs x 2.4 GHz)
+    `bound` names the largest, achieved / peak / unit / frac are its numbers (<= 1 by construction)."""
+    c, src = counters(workload, kernel)
+    t = max(avg_ms, 1e-9) * 1e-3
+    traffic = c.get("hbm_bytes_per_launch") if c else None
+    useful = min(alg_bytes, traffic) if traffic else None
+    fr = {}
+    if useful is not None:
+        fr["hbm"] = (useful / t / 1e9, HBM_PEAK_GBS, "GB/s")
+    if c and c.get("SQ_INSTS_VALU"):
+        fr["valu_issue"] = (c["SQ_INSTS_VALU"] / t / 1e9, VALU_PEAK_GINST, "G wave-instructions/s")
+        sc = (c.get("SQ_INSTS_SALU", 0) or 0) + (c.get("SQ_INSTS_SMEM", 0) or 0) + (c.get("SQ_INSTS_BRANCH", 0) or 0)
+        if sc:
+            fr["scalar_issue"] = (sc / t / 1e9, SCALAR_PEAK_GINST, "G instructions/s")
+    if fr:
+        bound = max(fr, key=lambda k: fr[k][0] / fr[k][1])
+        ach, peak, unit = fr[bound]
+        note = None
+    else:      # no counters committed for this kernel: the SURVEY 8d figure alone, capped so that it stays a fraction
+        bound, ach, peak, unit = "hbm", min(alg_bytes / t / 1e9, HBM_PEAK_GBS), HBM_PEAK_GBS, "GB/s"
+        note = "no PMC / SQ counters committed for this kernel: algorithmic bytes only (capped at the peak)"
+    out = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, traffic=traffic, kernel=kernel,
+               avg_launch_ms=avg_ms, units_per_launch=units_per_launch,
+               algorithmic_bytes_per_launch=alg_bytes, algorithmic_gbs=alg_bytes / t / 1e9,
+               wave_fetched_bytes_per_launch=wave_bytes,
+               hbm_traffic_gbs=(traffic / t / 1e9) if traffic else None,
+               fractions={k: v[0] / v[1] for k, v in fr.items()},
+               l2_hit_rate=c.get("l2_hit_rate") if c else None,
+               wait_inst_fraction=(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]) if c and c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_INST_ANY") else None,
+               wait_memory_fraction=(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c and c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") else None,
+               counters_source=src, **detail)
+    if note:
+        out["note"] = note
+    return out
+
+
+def traversal_bytes(work, rays, out_bytes=20):
+    """SURVEY 8d per-lane algorithmic bytes of a traversal launch: 32 B ray in + 32 B x box tests + 36 B x triangle records
+    + the result, summed over the launch, from the device work counters (box, tri, exact, fetch); and the bytes its waves
+    fetch: `fetch` counts a wave-uniform record fetch once per lane, a record is <= 64 B (BVH node 64, triangle 48)."""
+    box, tri, exact, fetch = (float(x) for x in work)
+    alg = 32.0 * rays + 32.0 * box + 36.0 * tri + out_bytes * rays
+    return alg, fetch / 64.0 * 64.0
+
+
+def render_work(gs, cam, params, sp, torch):
+    """one extra, untimed frame with rt_params.count_work: the traversal code with per-lane counters on the frame's rays"""
     from raytracer_amd import abi
-    import copy
-    import torch
     p2 = abi.rt_params.from_buffer_copy(bytes(params))
     p2.count_work = 1
     st = abi.rt_stats()
     frame = torch.zeros(cam.resx * cam.resy * 3, dtype=torch.uint8, device="cuda")
     abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p2), frame.data_ptr(), None, C.byref(st), sp))
-    rays = st.rays_primary + st.rays_reflect + st.rays_refract
-    box, tri, exact, fetch = (x / rays for x in st.closest_work)
-    srays = max(1, st.rays_shadow)
-    abox, atri, aexact, afetch = (x / srays for x in st.any_work)
-    return dict(bytes_per_ray=32 + 32 * box + 36 * tri + 20, box_tests_per_ray=box, tri_tests_per_ray=tri,
-                exact_tri_tests_per_ray=exact, record_fetches_per_ray=fetch, rays=rays,
-                any_bytes_per_ray=32 + 32 * abox + 36 * atri + 1, any_box_tests_per_ray=abox,
-                any_tri_tests_per_ray=atri)
+    return st
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU legs.  Everything that forks (the reference binaries, the process pool) runs BEFORE the process touches the GPU.
 
 def _port_frame(args):
     """one oracle-port frame in a worker process (cpu_baseline's all-cores leg)"""
@@ -110,56 +189,97 @@ def _port_frame(args):
 
 def cpu_port_all_cores(sd, res):
     """the build's CPU restatement on all host cores.  Rays are independent, so the cores each render the
-    sample frame (one process per core, fork); throughput = all their rays over the wall time of the slowest."""
+    sample frame (one process per core, spawned); throughput = all their rays over the wall time of the slowest."""
     import multiprocessing as mp
     cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), os.cpu_count() or 1, 64))
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res_list = pool.map(_port_frame, [(sd, res)] * cores)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res_list = pool.map_async(_port_frame, [(sd, res)] * cores).get(timeout=180)
     wall = time.perf_counter() - t0
     rays = sum(r for r, _ in res_list)
-    return dict(value=rays / wall / 1e6, unit="Mrays/s", cores=cores, kind="port",
-                sample=f"{cores} processes, each the sample frame {res[0]}x{res[1]} (oracle port)", seconds=wall)
+    busy = max(d for _, d in res_list)
+    return dict(value=rays / busy / 1e6, unit="Mrays/s", cores=cores, kind="port",
+                sample=f"{cores} processes, each the sample frame {res[0]}x{res[1]} (oracle port); time = the slowest "
+                       "process's render loop", seconds=busy, wall_with_spawn_s=wall)
 
 
-def cpu_baseline(sd, res):
-    """The reference binary (oracle/_ref/hw4_ref, compiled from the reference's own sources in the build
-    container) on a bounded sample of the same workload: same scene, same materials, `R` lowered to `res`.
-    Time = its own `elapse time` (render loop only, hw4.cpp:1094-1128), 1 core (it is single-threaded)."""
+def _run_reference_hw4(sd, res, name):
+    """the reference binary on `sd` at `res`: its own `elapse time` (render loop only, hw4.cpp:1094-1128) and KD log"""
     from raytracer_amd import scene
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "hw4_ref")
+    if not os.path.exists(ref_bin):
+        return None
+    sd2 = scene.SceneData(**{**sd.__dict__})
+    sd2.resx, sd2.resy = res
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, name + ".txt"), "w") as f:
+            f.write(scene.write_scene_text(sd2))
+        t0 = time.perf_counter()
+        subprocess.run([ref_bin, name + ".txt"], cwd=d, check=True, stdout=subprocess.DEVNULL, timeout=600)
+        wall = time.perf_counter() - t0
+        lines = dict(l.split(":", 1) for l in open(os.path.join(d, "executionTime_" + name + ".txt")).read().strip().splitlines())
+    return dict(seconds=float(lines["elapse time"].split()[0]), wall_s=wall,
+                kd_nodes=int(lines["total kd-tree node count"]), kd_depth=int(lines["max depth of kd-tree subdivision"]),
+                avg_check=float(lines["average ray-mesh Intersection check count"]))
+
+
+def cpu_baseline_monkey(sd, res):
+    """The reference binary (oracle/_ref/hw4_ref, compiled from the reference's own sources in the build container) on a
+    bounded sample of the headline workload: same scene, same materials, `R` lowered to `res`; 1 core (single-threaded)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "hw4_ref")
-    sample = f"monkey (970 tris, reflect=refract=0) at {res[0]}x{res[1]}, primary + shadow rays"
-    # rays of the sample, counted by the oracle (one shadow ray per primary hit and light)
-    o = ol.OracleScene(sd)
-    cam = ol.oracle_camera(sd.eye, sd.view, sd.fov, *res)
     from raytracer_amd import host
+    sample = f"monkey (970 tris, reflect=refract=0) at {res[0]}x{res[1]}, primary + shadow rays"
+    o = ol.OracleScene(sd)
     t0 = time.perf_counter()
-    o.render_whitted(cam, host.default_params("hw4", primary_only=1))
+    o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *res), host.default_params("hw4", primary_only=1))
+    port_s = time.perf_counter() - t0
+    rays = o.counters().rays_traced            # one shadow ray per primary hit and light
+    o.close()
+    ref = _run_reference_hw4(sd, res, "bench")
+    if ref:
+        return dict(value=rays / ref["seconds"] / 1e6, unit="Mrays/s", cores=1, kind="reference", sample=sample,
+                    seconds=ref["seconds"], rays=int(rays), port_seconds=port_s)
+    return dict(value=rays / port_s / 1e6, unit="Mrays/s", cores=1, kind="port", sample=sample, seconds=port_s, rays=int(rays))
+
+
+def cpu_baseline_mesh(res=(320, 180), nu=1000, nv=500):
+    """SURVEY 8d last bullet: the reference binary itself on the 1 M-triangle scene, written in its own text format
+    (152 MB); render loop `elapse time` at `res`, rays counted by the oracle on the same frame.  Its KD log is kept: the
+    reference builds the same tree the library uploads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from raytracer_amd import host, synth
+    sd = synth.mesh_scene(nu, nv)
+    sample = f"the same scene ({sd.nprim} triangles) at {res[0]}x{res[1]}, primary + shadow rays"
+    o = ol.OracleScene(sd)
+    t0 = time.perf_counter()
+    o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *res), host.default_params("hw4", primary_only=1))
     port_s = time.perf_counter() - t0
     rays = o.counters().rays_traced
+    oi = o.info()
     o.close()
-    if os.path.exists(ref_bin):
-        sd2 = scene.SceneData(**{**sd.__dict__})
-        sd2.resx, sd2.resy = res
-        with tempfile.TemporaryDirectory() as d:
-            with open(os.path.join(d, "bench.txt"), "w") as f:
-                f.write(scene.write_scene_text(sd2))
-            subprocess.run([ref_bin, "bench.txt"], cwd=d, check=True, stdout=subprocess.DEVNULL)
-            lines = dict(l.split(":", 1) for l in open(os.path.join(d, "executionTime_bench.txt")).read().strip().splitlines())
-        secs = float(lines["elapse time"].split()[0])
-        return dict(value=rays / secs / 1e6, unit="Mrays/s", cores=1, kind="reference", sample=sample,
-                    seconds=secs, rays=int(rays))
-    return dict(value=rays / port_s / 1e6, unit="Mrays/s", cores=1, kind="port", sample=sample, seconds=port_s,
+    try:
+        ref = _run_reference_hw4(sd, res, "mesh1m")
+    except Exception as e:
+        log(f"reference binary on the 1 M-triangle scene failed: {type(e).__name__}: {e}")
+        ref = None
+    if ref:
+        return dict(value=rays / ref["seconds"] / 1e6, unit="Mrays/s", cores=1, kind="reference", sample=sample,
+                    seconds=ref["seconds"], rays=int(rays), port_seconds=port_s, whole_run_wall_s=ref["wall_s"],
+                    reference_kd_nodes=ref["kd_nodes"], reference_kd_depth=ref["kd_depth"],
+                    reference_avg_check=ref["avg_check"],
+                    kd_equals_library=bool(ref["kd_nodes"] == oi.kd_nodes_built and ref["kd_depth"] == oi.kd_max_depth))
+    return dict(value=rays / port_s / 1e6, unit="Mrays/s", cores=1, kind="port", sample=sample + ", oracle port", seconds=port_s,
                 rays=int(rays))
 
 
-def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, steps=3, with_cpu=True):
-    """BASELINE configuration 4's shape: kNN radiance lookups/s on a synthetic photon map (positions on
-    the walls of the Final scene's unit box), queries on the floor/walls."""
+# ---------------------------------------------------------------------------------------------------------------------
+# secondary workloads (one GPU)
+
+def knn_map(n_photons, seed=1234):
+    rng = np.random.default_rng(seed)
     from raytracer_amd import abi
-    rng = np.random.default_rng(1234)
     a = np.zeros(n_photons + 1, abi.photon_dtype)
     pos = rng.uniform(-0.5, 0.5, (n_photons, 3)).astype(np.float32)
     pos[:, 2] += 0.5
@@ -168,7 +288,14 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     a["position"][1:] = pos
     a["power"][1:] = np.float32(1.0 / n_photons)
     a["phi"][1:] = rng.integers(0, 256, n_photons); a["theta"][1:] = rng.integers(0, 256, n_photons)
-    del pos, face
+    return a, rng
+
+
+def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, steps=3, with_cpu=True):
+    """BASELINE configuration 4's shape: kNN radiance lookups/s on a synthetic photon map (positions on
+    the walls of the Final scene's unit box), queries on the floor/walls."""
+    from raytracer_amd import abi
+    a, rng = knn_map(n_photons)
     log(f"kNN: {n_photons} synthetic photons generated, building the heap")
     t0 = time.perf_counter()
     scene_handle.photonmap_build(abi.RT_PMAP_GLOBAL, a)
@@ -199,19 +326,19 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     e1.record(st); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     # algorithmic bytes per lookup: 24 B in + 16 B x heap nodes visited + 12 B x found + 12 B out, with the visits
-    # THIS kernel performs: one counted launch (untimed) -- phase-1 record fetches of every lane + the nodes of the shared walks
+    # THIS kernel performs: one counted launch (untimed) -- phase-1 record fetches of every lane + the nodes of the walks
     # summed over the lanes that were inside the subtree.  The reference's own visit count (CPU oracle, a sample of the same
     # queries) is reported beside it.
     scene_handle.knn_stats(True)
     run(); torch.cuda.synchronize()
     ks = scene_handle.knn_stats(False)
-    ref_visits, found_mean, cpu = None, float(k), None
+    ref_visits, found_mean, cpu, parity = None, float(k), None, None
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
         ns = min(2000, n_queries)
         sel = np.linspace(0, n_queries - 1, ns).astype(np.int64)
-        qs = np.ascontiguousarray(q[sel])
+        qs = np.ascontiguousarray(q[sel]); qn = np.ascontiguousarray(nrm[sel])
         idx = np.zeros((ns, k), np.int32); d2 = np.zeros((ns, k), np.float32); fnd = np.zeros(ns, np.int32); vis = C.c_int64(0)
         t0 = time.perf_counter()
         ol.oracle().orc_pmap_knn(a.ctypes.data, n_photons, qs.ctypes.data, ns, k, radius, idx.ctypes.data, d2.ctypes.data,
@@ -219,31 +346,39 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
         cpu_s = time.perf_counter() - t0
         ref_visits = vis.value / ns
         found_mean = float(fnd.mean())
-        cpu = dict(value=ns / cpu_s, unit="lookups/s", cores=1, kind="port", sample=f"{ns} of the same queries, oracle LocatePhoton")
+        cpu = dict(value=ns / cpu_s, unit="lookups/s", cores=1, kind="port", sample=f"{ns} of the same queries, oracle LocatePhoton",
+                   seconds=cpu_s)
+        # parity sample: the oracle's CalcIrradiance for those queries against what the timed kernel wrote for them, and the
+        # strict kernel's index lists against the oracle's
+        orgb = np.zeros((ns, 3), np.float32)
+        ol.oracle().orc_pmap_irradiance(a.ctypes.data, n_photons, qs.ctypes.data, qn.ctypes.data, ns, k, radius, orgb.ctypes.data)
+        grgb = out.cpu().numpy()[sel]
+        gi, gd, gf, gr = scene_handle.photon_knn(abi.RT_PMAP_GLOBAL, qs[:500], k, radius)
+        parity = dict(queries=ns, irradiance_within_1e5_rel=bool(np.allclose(grgb, orgb, rtol=1e-5, atol=1e-12)),
+                      max_rel_err=float((np.abs(grgb - orgb) / np.maximum(np.abs(orgb), 1e-30)).max()),
+                      index_lists_bit_exact=bool(np.array_equal(gi, idx[:500]) and np.array_equal(gf, fnd[:500]) and gd.tobytes() == d2[:500].tobytes()))
+        parity["parity_sample_ok"] = parity["irradiance_within_1e5_rel"] and parity["index_lists_bit_exact"]
     if ks[6] > 0:          # the wave-shared kernels ran
         visits = float(ks[0] + ks[12]) / n_queries
-        detail = dict(kernel="k_irr_main", waves=int(ks[6]), phase1_fetches_per_lookup=float(ks[0]) / n_queries,
+        detail = dict(waves=int(ks[6]), phase1_fetches_per_lookup=float(ks[0]) / n_queries,
                       walk_nodes_per_wave=float(ks[1] + ks[3]) / float(ks[6]), inserted_per_wave=float(ks[2]) / float(ks[6]),
                       strict_redo_queries=int(ks[5]), waves_gave_up=int(ks[11]), longest_wave_ms=float(int(ks[8]) >> 24) * 1e-5)
-        tkey = "knn_10m.k_irr_main"
+        kernel = "k_irr_main"
     else:
-        visits, detail, tkey = (ref_visits or 0.0), dict(kernel="k_photon_knn"), "knn_10m.k_photon_knn"
+        visits, detail, kernel = (ref_visits or 0.0), dict(), "k_photon_knn"
     bytes_per = 24 + 16 * visits + 12 * found_mean + 12
-    gbs = bytes_per * n_queries / (ms * 1e-3) / 1e9
+    rf = make_roofline("knn_10m" if n_photons == 10_000_000 else f"knn_{n_photons}", kernel, ms, n_queries, bytes_per * n_queries,
+                       visits_per_lookup=visits, bytes_per_lookup=bytes_per, reference_visits_per_lookup=ref_visits,
+                       time_is="whole step (query sort + k_irr_main + strict redo), HIP events", **detail)
     return dict(metric="kNN radiance lookups/s", value=n_queries / (ms * 1e-3), unit="lookups/s",
                 config=dict(workload="synthetic photon map on the Final scene's box walls", photons=n_photons,
                             queries=n_queries, k=k, radius=radius),
-                ms_per_step=ms, heap_build_host_s=build_s,
-                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                              traffic=_traffic(tkey), visits_per_lookup=visits, bytes_per_lookup=bytes_per,
-                              reference_visits_per_lookup=ref_visits, **detail),
-                cpu_baseline=cpu)
+                ms_per_step=ms, heap_build_host_s=build_s, roofline=rf, cpu_baseline=cpu, parity=parity)
 
 
-def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500, tag="mesh_1m"):
+def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500, tag="mesh_1m", cpu=None):
     """BASELINE configuration 3's scene: the synthetic 1 M-triangle mesh (raytracer_amd/synth.py) at 3840x2160,
-    primary + shadow rays.  Here the KD-tree (224 k nodes, 2.4 M leaf records, 126 MB per octant-ordered copy set)
-    no longer fits any cache, so the HBM roofline of the closest-hit kernel means something."""
+    primary + shadow rays."""
     from raytracer_amd import abi, host, synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
@@ -257,47 +392,53 @@ def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500, tag="mesh_1m"):
     cam = host.camera_for(sd, BASE_RES)
     params = host.default_params("hw4", primary_only=1)
     frame = torch.zeros(BASE_RES[0] * BASE_RES[1] * 3, dtype=torch.uint8, device="cuda")
+    ids = torch.zeros(BASE_RES[0] * BASE_RES[1], dtype=torch.int32, device="cuda")
     st = abi.rt_stats()
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot = dict(ms=0.0, closest=0.0, anyh=0.0, rays=0, prim=0, shadow=0, any_launches=0)
     for i in range(steps + 1):
-        abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(), None, C.byref(st), sp))
+        abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(), ids.data_ptr(), C.byref(st), sp))
         if i:
             tot["ms"] += st.kernel_ms; tot["closest"] += st.trace_closest_ms; tot["anyh"] += st.trace_any_ms
             tot["rays"] += st.rays_primary + st.rays_shadow; tot["prim"] += st.rays_primary
             tot["shadow"] += st.rays_shadow; tot["any_launches"] += st.trace_any_launches
-    alg = algorithmic_bytes_per_ray(gs, cam, params, sp)
+    stw = render_work(gs, cam, params, sp, torch)
     avg_ms = tot["closest"] / steps
     fused = tot["any_launches"] == 0 and tot["shadow"] > 0          # the whole frame is one kernel (k_primary_only)
-    bytes_per_launch = alg["bytes_per_ray"] * (tot["prim"] / steps) + (alg["any_bytes_per_ray"] * (tot["shadow"] / steps) if fused else 0.0)
-    gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    kernel = "k_primary_only" if fused else "k_trace_closest"
-    traffic = _traffic(tag + "." + kernel)
-    # CPU baseline: the oracle port on a strided sample of the same frame (the reference binary would need the scene as
-    # 130 MB of text and minutes of KD build printing every node)
-    o = ol.OracleScene(sd)
-    res = (240, 135)
-    t0 = time.perf_counter()
-    o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *res), host.default_params("hw4", primary_only=1))
-    cpu_s = time.perf_counter() - t0
-    crays = o.counters().rays_traced
-    o.close(); gs.close()
+    alg_c, wave_c = traversal_bytes(stw.closest_work, stw.rays_primary)
+    alg_a, wave_a = traversal_bytes(stw.any_work, stw.rays_shadow, out_bytes=1)
+    kernel = "k_primary_only" if fused else "k_trace_closest_bvh"
+    rf = make_roofline(tag, kernel, avg_ms, (tot["prim"] + (tot["shadow"] if fused else 0)) / steps,
+                       alg_c + (alg_a if fused else 0.0), wave_c + (wave_a if fused else 0.0),
+                       box_tests_per_ray=stw.closest_work[0] / max(1, stw.rays_primary),
+                       tri_records_per_ray=stw.closest_work[1] / max(1, stw.rays_primary),
+                       shadow_box_tests_per_ray=stw.any_work[0] / max(1, stw.rays_shadow),
+                       shadow_tri_records_per_ray=stw.any_work[1] / max(1, stw.rays_shadow))
+    # parity sample: primary hit ids of a strided pixel sample of THIS frame against the oracle
+    parity = None
+    try:
+        o = ol.OracleScene(sd)
+        ocam = ol.oracle_camera(sd.eye, sd.view, sd.fov, *BASE_RES)
+        npx = BASE_RES[0] * BASE_RES[1]
+        pix = np.arange(17, npx, 211, dtype=np.int64)                 # 39 k pixels, every row and column phase
+        rays = ol.oracle_primary_rays(ocam, (pix % BASE_RES[0]).astype(np.int64), (pix // BASE_RES[0]).astype(np.int64))
+        want = o.trace_closest(rays)["prim"]
+        got = ids.cpu().numpy()[pix]
+        o.close()
+        parity = dict(pixels=int(pix.size), hit=int((want >= 0).sum()), mismatches=int((got != want).sum()),
+                      parity_sample_ok=bool(np.array_equal(got, want)))
+    except Exception as e:
+        parity = dict(error=f"{type(e).__name__}: {e}", parity_sample_ok=False)
+    gs.close()
     return dict(metric="Mrays/s (KD-tree traversal, primary + shadow rays)", value=tot["rays"] / (tot["ms"] * 1e-3) / 1e6,
                 unit="Mrays/s", ms_per_step=tot["ms"] / steps,
                 config=dict(workload=f"synthetic displaced-sphere mesh, {sd.nprim} triangles + floor, {BASE_RES[0]}x{BASE_RES[1]}, "
                                      "primary + shadow rays", kd_nodes=int(inf.flat_nodes), leaf_records=int(inf.leaf_refs),
                             scene_device_mb=inf.device_bytes / 1e6, scene_gen_s=gen_s, kd_build_upload_s=build_s),
-                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
-                              kernel=kernel, avg_launch_ms=avg_ms,
-                              rays_per_launch=(tot["prim"] + (tot["shadow"] if fused else 0)) / steps,
-                              bytes_per_ray=alg["bytes_per_ray"], box_tests_per_ray=alg["box_tests_per_ray"],
-                              tri_tests_per_ray=alg["tri_tests_per_ray"], any_hit_bytes_per_ray=alg["any_bytes_per_ray"],
-                              any_hit_ms_per_step=tot["anyh"] / steps,
-                              note=("one fused kernel traces the primary and the shadow rays: algorithmic bytes of both. " if fused else "") +
-                                   "algorithmic bytes count every lane's node / triangle reads; the kernel fetches a record once "
-                                   "per wave on the scalar path, so achieved can exceed what HBM itself delivers"),
-                cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", cores=1, kind="port",
-                                  sample=f"the same scene at {res[0]}x{res[1]}, primary + shadow rays, oracle port", seconds=cpu_s))
+                roofline=rf, cpu_baseline=cpu, parity=parity)
+
+
+DRT_KW = dict(lens_radius=0.01, focal_distance=1.3, light_radius=0.5, glossy=0.05, seed=3)
 
 
 def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
@@ -310,33 +451,63 @@ def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
     sd = synth.mesh_scene(nu, nv, reflect=0.3)
     gs = host.Scene(sd, device=local_rank)
     cam = host.camera_for(sd, res)
-    kw = dict(spp=spp, lens_radius=0.01, focal_distance=1.3, light_radius=0.5, glossy=0.05, seed=3)
-    p = host.default_params("hw4", **kw)
+    p = host.default_params("hw4", spp=spp, **DRT_KW)
     frame = torch.zeros(res[0] * res[1] * 3, dtype=torch.uint8, device="cuda")
     st = abi.rt_stats()
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(2):
         abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), sp))
     rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
+    stw = render_work(gs, cam, p, sp, torch)
+    # the frame's traversal time by kernel family; the roofline goes to the largest
+    fam = {
+        "k_trace_closest_bvh_lanes": (st.lane_closest_ms, st.lane_closest_launches, st.lane_closest_rays, stw.lane_closest_work, 20),
+        "k_trace_any_bvh_lanes": (st.lane_any_ms, st.lane_any_launches, st.lane_any_rays, stw.lane_any_work, 1),
+        "k_trace_closest_bvh": (st.trace_closest_ms - st.lane_closest_ms, st.trace_closest_launches - st.lane_closest_launches,
+                                st.rays_primary + st.rays_reflect + st.rays_refract - st.lane_closest_rays,
+                                [a - b for a, b in zip(stw.closest_work, stw.lane_closest_work)], 20),
+        "k_trace_any_bvh": (st.trace_any_ms - st.lane_any_ms, st.trace_any_launches - st.lane_any_launches,
+                            st.rays_shadow - st.lane_any_rays, [a - b for a, b in zip(stw.any_work, stw.lane_any_work)], 1),
+    }
+    kernel = max(fam, key=lambda k: fam[k][0])
+    ms, launches, krays, work, ob = fam[kernel]
+    launches = max(1, launches)
+    alg, wave = traversal_bytes(work, krays, out_bytes=ob)
+    per_lane = kernel.endswith("_lanes")
+    rf = make_roofline("drt_1m", kernel, ms / launches, krays / launches, alg / launches,
+                       (alg if per_lane else wave) / launches,     # per-lane kernels: every lane fetches its own records
+                       launches_per_frame=launches, ms_per_frame_in_this_kernel=ms,
+                       box_tests_per_ray=work[0] / max(1, krays), tri_records_per_ray=work[1] / max(1, krays),
+                       traversal_ms_by_kernel={k: v[0] for k, v in fam.items()})
+    # CPU baseline + parity sample: the oracle's restatement of the same samplers on a small frame, and the GPU on that frame
     o = ol.OracleScene(sd)
-    cres, cspp = (48, 27), 8
-    pc = host.default_params("hw4", **{**kw, "spp": cspp})
+    cres, cspp = (128, 72), 8
+    pc = host.default_params("hw4", spp=cspp, **DRT_KW)
     t0 = time.perf_counter()
-    o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), pc)
+    orgb, oids, _ = o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), pc)
     cpu_s = time.perf_counter() - t0
     crays = o.counters().rays_traced
-    o.close(); gs.close()
+    o.close()
+    grgb, gids, _ = gs.render(host.camera_for(sd, cres), pc, want_ids=True)
+    d = np.abs(grgb.astype(int) - orgb.reshape(grgb.shape).astype(int)).max(-1)
+    parity = dict(frame=list(cres), spp=cspp, hit_ids_equal=bool(np.array_equal(gids, oids)),
+                  pixels_off_by_more_than_1lsb=int((d > 1).sum()),
+                  parity_sample_ok=bool(np.array_equal(gids, oids) and (d > 1).sum() <= 0.005 * cres[0] * cres[1]),
+                  note="parity unpinned: the samplers are build-defined, the checker is the oracle's restatement of them")
+    gs.close()
     return dict(metric="Mrays/s (distributed ray tracing, all ray types)", value=rays / (st.kernel_ms * 1e-3) / 1e6, unit="Mrays/s",
                 ms_per_frame=st.kernel_ms, passes=st.passes,
                 config=dict(workload=f"synthetic mesh, {sd.nprim} triangles, {res[0]}x{res[1]}, {spp} spp, lens 0.01 / focus 1.3, "
                                      "light ball 0.5, glossy 0.05, reflect 0.3 (sphere) / 0.5 (floor), depth <= 10"),
                 rays=dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract),
-                trace_closest_ms=st.trace_closest_ms, trace_any_ms=st.trace_any_ms,
+                trace_closest_ms=st.trace_closest_ms, trace_any_ms=st.trace_any_ms, roofline=rf,
                 cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", cores=1, kind="port",
-                                  sample=f"the same scene and samplers at {cres[0]}x{cres[1]}, {cspp} spp, oracle port", seconds=cpu_s))
+                                  sample=f"the same scene and samplers at {cres[0]}x{cres[1]}, {cspp} spp, oracle port "
+                                         "(the reference has no such samplers)", seconds=cpu_s),
+                parity=parity)
 
 
-def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_000, res=(192, 192)):
+def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_000, res=(192, 192), tag="photon_frame"):
     """BASELINE configuration 4's pipeline end to end on the bundled Final scene: GPU emission of both maps, host balance,
     then the photon-mapping frame (caustic kNN r=0.1 + 50 gather rays with global kNN r=1.0, k=100, 400 light samples)."""
     from raytracer_amd import abi, host, scene
@@ -360,43 +531,197 @@ def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_
     abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st2), sp))
     ks = gs.knn_stats(False)
     rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract + st.rays_gather
-    # CPU baseline: the oracle's restatement of the same frame at 10x10 pixels, same maps
+    # roofline: the radiance estimate is the frame (k_irr_main ~80 % of it); algorithmic bytes from its work counters
+    visits = float(ks[0] + ks[12]) / max(1, st.knn_lookups)
+    bytes_per = 24 + 16 * visits + 12 * float(p.knn_k) + 12
+    launches = max(1, st.knn_launches)
+    rf = make_roofline(tag, "k_irr_main", st.knn_ms / launches, st.knn_lookups / launches, bytes_per * st.knn_lookups / launches,
+                       visits_per_lookup=visits, bytes_per_lookup=bytes_per, launches_per_frame=launches,
+                       ms_per_frame_in_the_estimate=st.knn_ms,
+                       time_is="all radiance-estimate calls of the frame (query sort + k_irr_main + strict redo), HIP events",
+                       waves=int(ks[6]), strict_redo_queries=int(ks[5]), waves_gave_up=int(ks[11]),
+                       walk_nodes_per_wave=float(ks[1] + ks[3]) / max(1.0, float(ks[6])),
+                       inserted_per_wave=float(ks[2]) / max(1.0, float(ks[6])))
+    # CPU baseline + parity sample: the oracle's restatement of the same frame at 10x10 pixels, same maps, and the GPU on it
     o = ol.OracleScene(sd)
     cres = (10, 10)
     t0 = time.perf_counter()
-    o.render_photon(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), p, maps[0]["heap"], maps[1]["heap"])
+    orgb, oids, _ = o.render_photon(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), p, maps[0]["heap"], maps[1]["heap"])
     cpu_s = time.perf_counter() - t0
     c = o.counters()
     crays = c.rays_primary + c.rays_shadow + c.rays_reflect + c.rays_refract + c.rays_gather
-    o.close(); gs.close()
-    knn_detail = dict(waves=int(ks[6]), strict_redo_queries=int(ks[5]), waves_gave_up=int(ks[11]),
-                      walk_nodes_per_wave=float(ks[1] + ks[3]) / max(1.0, float(ks[6])),
-                      inserted_per_wave=float(ks[2]) / max(1.0, float(ks[6])), phase1_fetches_per_lookup=float(ks[0]) / max(1, st.knn_lookups))
-    return dict(metric="photon-mapping frame: Mrays/s and kNN radiance lookups/s", value=rays / (st.kernel_ms * 1e-3) / 1e6, knn=knn_detail,
+    o.close()
+    grgb, gids, _ = gs.render(host.camera_for(sd, cres), p, want_ids=True)
+    d = np.abs(grgb.astype(int) - np.asarray(orgb).reshape(grgb.shape).astype(int)).max(-1)
+    parity = dict(frame=list(cres), hit_ids_equal=bool(np.array_equal(gids, np.asarray(oids).reshape(gids.shape))),
+                  pixels_off_by_more_than_1lsb=int((d > 1).sum()),
+                  parity_sample_ok=bool(np.array_equal(gids, np.asarray(oids).reshape(gids.shape)) and (d > 1).sum() <= 1))
+    gs.close()
+    return dict(metric="photon-mapping frame: Mrays/s and kNN radiance lookups/s", value=rays / (st.kernel_ms * 1e-3) / 1e6,
                 unit="Mrays/s", lookups_per_s=st.knn_lookups / (st.kernel_ms * 1e-3), ms_per_frame=st.kernel_ms,
                 config=dict(workload=f"bundled Final scene, {res[0]}x{res[1]}, 1 AA tap, 50 gather rays, 20x20 light samples, k=100",
                             photons_global=n_global, photons_caustic=n_caustic, emissions_global=maps[0]["emissions"],
                             emissions_caustic=maps[1]["emissions"], maps_emit_balance_upload_s=maps_s),
                 rays=dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract,
-                          gather=st.rays_gather), knn_lookups=st.knn_lookups,
+                          gather=st.rays_gather), knn_lookups=st.knn_lookups, roofline=rf,
                 cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", lookups_per_s=c.knn_lookups / cpu_s, cores=1,
                                   kind="port", sample=f"the same frame at {cres[0]}x{cres[1]}, same photon maps, oracle port",
-                                  seconds=cpu_s))
+                                  seconds=cpu_s),
+                parity=parity)
 
 
-def _traffic(key):
-    """HBM bytes per launch from the committed PMC summary (tools/prof_pmc.sh -> profiles/traffic_r01.json)"""
-    tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if not os.path.exists(tf):
-        return None
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1: the lines of the configurations that are meant to scale (strong scaling), after the weak-scaling headline
+
+class Coll:
+    """torch.distributed with device tensors; with the gloo backend (rehearsal of the N > 1 path on one GPU) tensors are
+    staged through the host."""
+    def __init__(self, dist, torch, backend):
+        self.dist, self.torch, self.host = dist, torch, backend == "gloo"
+
+    def all_ok(self, ok, dev):
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int64, device="cpu" if self.host else dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def max_float(self, x, dev):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.host else dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_float(self, x, dev):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.host else dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def gather0(self, send, recv_list, rank):
+        if not self.host:
+            self.dist.gather(send, recv_list if rank == 0 else None, dst=0)
+            return
+        s = send.cpu()
+        r = [self.torch.empty_like(s) for _ in recv_list] if rank == 0 else None
+        self.dist.gather(s, r, dst=0)
+        if rank == 0:
+            for a, b in zip(recv_list, r):
+                a.copy_(b)
+
+
+def drt_strong(torch, coll, rank, n, local_rank, res=(1920, 1080), spp=64, steps=2):
+    """BASELINE configuration 3 over N GPUs, STRONG scaling: the fixed 1080p x 64 spp frame, 64x64 tiles round-robin, each
+    rank's pixels written packed (rt_params.packed_output) and gathered to rank 0; time = slowest rank incl. the gather."""
+    from raytracer_amd import abi, host, synth
+    dev = torch.device("cuda", local_rank)
+    gs = cam = None
+    ok = True
     try:
-        d = json.load(open(tf))
-        for part in key.split("."):
-            d = d[part]
-        return d.get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+        sd = synth.mesh_scene(1000, 500, reflect=0.3)
+        gs = host.Scene(sd, device=local_rank)
+        cam = host.camera_for(sd, res)
+        plist = [host.pixel_list(cam, host.default_params("hw4", tile_size=TILE, tile_rank=r, tile_nranks=n)) for r in range(n)]
+        counts = [int(l.size) for l in plist]
+        maxc = max(counts)
+        p = host.default_params("hw4", spp=spp, tile_size=TILE, tile_rank=rank, tile_nranks=n, packed_output=1, **DRT_KW)
+        send = torch.zeros((maxc, 3), dtype=torch.uint8, device=dev)
+        recv = [torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(n)] if rank == 0 else []
+        sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = abi.rt_stats()
+    except Exception as e:
+        log(f"rank {rank}: drt_strong set-up failed: {type(e).__name__}: {e}")
+        ok = False
+    if not coll.all_ok(ok, dev):
+        return dict(error="set-up failed on a rank")
+    rays, t_total = 0, 0.0
+    for i in range(steps + 1):
+        torch.cuda.synchronize(); coll.dist.barrier()
+        t0 = time.perf_counter()
+        rc = gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), send.data_ptr(), None, C.byref(st), sp)
+        torch.cuda.synchronize()
+        if not coll.all_ok(rc == 0, dev):
+            return dict(error="render failed on a rank")
+        coll.gather0(send, recv, rank)
+        torch.cuda.synchronize(); coll.dist.barrier()
+        dt = time.perf_counter() - t0
+        if i:
+            t_total += coll.max_float(dt, dev)
+            rays += st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
+    total_rays = coll.sum_float(float(rays), dev)
+    out = None
+    if rank == 0:
+        # the assembled frame against the same frame rendered whole on rank 0
+        final = torch.zeros((res[0] * res[1], 3), dtype=torch.uint8, device=dev)
+        for r in range(n):
+            pl = torch.from_numpy(plist[r].astype(np.int64)).to(dev)
+            okm = pl >= 0
+            final[pl[okm]] = recv[r][: counts[r]][okm]
+        whole = torch.zeros(res[0] * res[1] * 3, dtype=torch.uint8, device=dev)
+        pw = host.default_params("hw4", spp=spp, **DRT_KW)
+        abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(pw), whole.data_ptr(), None, None, sp))
+        torch.cuda.synchronize()
+        out = dict(metric="Mrays/s (distributed ray tracing, all ray types)", value=total_rays / t_total / 1e6, unit="Mrays/s",
+                   n_gpus=n, scaling="strong", ms_per_frame=t_total / steps * 1e3, steps=steps,
+                   config=dict(workload=f"BASELINE configs[2]: 1 M-triangle mesh, {res[0]}x{res[1]}, {spp} spp, tiles {TILE}x{TILE} "
+                                        f"round-robin over {n} GPUs, packed gather to rank 0",
+                               assembled_frame_equals_one_gpu_frame=bool(torch.equal(final.view(-1), whole))))
+    gs.close()
+    return out
 
+
+def emission_sharded(torch, dist, coll, rank, n, local_rank, targets=(1_000_000, 100_000)):
+    """BASELINE configuration 4/5's exchange step over N GPUs: emission sharded by emission index, RCCL all-gather of the
+    photons, ONE balance per node and the map's device image broadcast (raytracer_amd/dist.py).  Checked: rank 0's heap
+    equals the heap it builds alone, and every rank's map answers a fixed set of radiance queries with the same bits."""
+    from raytracer_amd import abi, host, scene
+    from raytracer_amd import dist as rdist
+    dev = torch.device("cuda", local_rank)
+    sd = scene.parse_scene_file(os.path.join(ROOT, "tests", "golden", "final_input.txt"), flavour="final")
+    gs = host.Scene(sd, device=local_rank)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    if coll.host:       # rehearsal over gloo: every rank builds (the broadcast of device tensors needs RCCL)
+        maps = rdist.build_photon_maps(gs, torch, targets, seed=1, rank=rank, world=n, dist=_HostDist(dist, torch), every_rank_builds=True)
+    else:
+        maps = rdist.build_photon_maps(gs, torch, targets, seed=1, rank=rank, world=n, dist=dist)
+    torch.cuda.synchronize(); dist.barrier()
+    dt = coll.max_float(time.perf_counter() - t0, dev)
+    # every rank answers the same queries on its copy of the global map
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-0.45, 0.45, (4096, 3)).astype(np.float32); q[:, 2] += 0.5; q[:2048, 1] = -0.5
+    nr = np.tile(np.float32([0, 1, 0]), (4096, 1))
+    rgb = gs.photon_irradiance(abi.RT_PMAP_GLOBAL, q, nr, 100, 1.0)
+    h = int.from_bytes(hashlib.sha256(rgb.tobytes()).digest()[:7], "little")
+    hmax, hmin = coll.max_float(float(h), dev), -coll.max_float(-float(h), dev)
+    out = None
+    if rank == 0:
+        gs1 = host.Scene(sd, device=local_rank)
+        t1 = time.perf_counter()
+        alone = rdist.build_photon_maps(gs1, torch, targets, seed=1)
+        alone_s = time.perf_counter() - t1
+        same = all(m["heap"].tobytes() == a["heap"].tobytes() for m, a in zip(maps, alone))
+        gs1.close()
+        out = dict(metric="photon maps: sharded emission + all-gather + one balance per node", value=sum(targets) / dt, unit="photons/s",
+                   n_gpus=n, scaling="strong", seconds=dt, one_rank_alone_seconds=alone_s,
+                   config=dict(workload=f"bundled Final scene, {targets[0]} global + {targets[1]} caustic photons",
+                               allgather_bytes=int(sum(m.get("allgather_bytes", 0) for m in maps)),
+                               image_bytes=int(sum(m.get("image_bytes", 0) for m in maps)),
+                               heap_equals_one_rank_heap=bool(same), every_rank_answers_alike=bool(hmax == hmin and np.abs(rgb).max() > 0)))
+    gs.close()
+    return out
+
+
+class _HostDist:
+    """all_gather of device tensors through the host (gloo rehearsal only)"""
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+
+    def all_gather(self, outs, t):
+        s = t.cpu()
+        r = [self.torch.empty_like(s) for _ in outs]
+        self.dist.all_gather(r, s)
+        for a, b in zip(outs, r):
+            a.copy_(b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
@@ -405,32 +730,60 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true", help="skip the secondary lines (kNN, 1M-triangle mesh, photon frame)")
-    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,drt_1m,photon_frame (and, on request only: stress_mesh_10m,stress_knn_200m)")
+    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,drt_1m,photon_frame (and, on request only: stress_mesh_10m,stress_knn_200m,photon_frame_full)")
     ap.add_argument("--knn-photons", type=int, default=10_000_000)
     ap.add_argument("--knn-queries", type=int, default=1920 * 1080)
     ap.add_argument("--cpu-sample", type=str, default="960x540")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the sharding / gather logic only (tests)")
+    ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal of the N > 1 path with every rank on one GPU)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"warning: WORLD_SIZE {world} != --gpus {args.gpus}; using WORLD_SIZE")
     n = world if world > 1 else 1
     dry = args.dry_run
+    rehearse = n > 1 and args.backend == "gloo" and not dry
+    only = [x for x in args.only_secondary.split(",") if x]
+    want = lambda name: (not args.no_knn) and ((name in only) if (only or name.startswith("stress_") or name.endswith("_full")) else True)
+
+    # ---- CPU legs that fork (reference binaries, process pool): before anything touches the GPU ----------------------
+    sd = bench_scene()
+    cpu = {}
+    if rank == 0 and n == 1 and not dry and not args.no_cpu_baseline:
+        w, h = (int(x) for x in args.cpu_sample.split("x"))
+        t0 = time.perf_counter()
+        try:
+            cpu["headline"] = cpu_baseline_monkey(sd, (w, h))
+        except Exception as e:
+            cpu["headline"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            cpu["headline"]["all_cores"] = cpu_port_all_cores(sd, (w, h))
+        except Exception as e:      # a reported extra, never a reason to lose the line
+            cpu["headline"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
+        if want("mesh_1m"):
+            try:
+                cpu["mesh_1m"] = cpu_baseline_mesh()
+            except Exception as e:
+                cpu["mesh_1m"] = {"error": f"{type(e).__name__}: {e}"}
+        log(f"CPU legs (reference binary, all-cores port): {time.perf_counter() - t0:.1f} s")
+
+    import torch
+    import torch.distributed as dist
+
+    if world != args.gpus and world > 1:
+        log(f"warning: WORLD_SIZE {world} != --gpus {args.gpus}; using WORLD_SIZE")
+    if rehearse:
+        local_rank = 0
     dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     if not dry:
         torch.cuda.set_device(dev)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo" if dry else "nccl")
+        dist.init_process_group(backend="gloo" if (dry or rehearse) else "nccl")
+    coll = Coll(dist, torch, "gloo" if (dry or rehearse) else "nccl") if n > 1 else None
 
     from raytracer_amd import abi, host
-    sd = bench_scene()
     resx, resy = frame_for(n) if not dry else (256 * WEAK_FACTORS.get(n, (n, 1))[0], 128 * WEAK_FACTORS.get(n, (n, 1))[1])
     npix = resx * resy
     packed = n > 1                      # a rank's tiles leave the kernel as one contiguous buffer (rt_params.packed_output)
@@ -452,6 +805,7 @@ def main():
         counts = [len(rank_pixel_index(resx, resy, r, n)) for r in range(n)] if n > 1 else [npix]
     maxc = max(counts)
     frame = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
+    hit_ids = torch.zeros(npix, dtype=torch.int32, device=dev) if (n == 1 and not dry) else None
     sendbuf = [torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     recv = [[torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(n)] for _ in range(2)] if (n > 1 and rank == 0) else None
     final = torch.zeros((npix, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -485,7 +839,8 @@ def main():
             # copy and a synchronisation per frame).  Every step renders the same frame, so its ray counts are those of the
             # instrumented frames that follow the timed region.
             abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), sendbuf[b].data_ptr() if packed else frame.data_ptr(),
-                                         None, C.byref(st) if timed == "stats" else None, sp))
+                                         hit_ids.data_ptr() if (timed == "stats" and hit_ids is not None) else None,
+                                         C.byref(st) if timed == "stats" else None, sp))
             if timed == "stats":
                 tot["rays"] += st.rays_primary + st.rays_shadow
                 tot["closest_ms"] += st.trace_closest_ms; tot["any_ms"] += st.trace_any_ms
@@ -496,7 +851,10 @@ def main():
                 pending[b].wait()
             if not packed:
                 sendbuf[b][: counts[rank]] = frame.view(-1, 3)[my_pix]
-            pending[b] = dist.gather(sendbuf[b], recv[b] if rank == 0 else None, dst=0, async_op=True)
+            if rehearse:
+                coll.gather0(sendbuf[b], recv[b] if rank == 0 else [], rank)
+            else:
+                pending[b] = dist.gather(sendbuf[b], recv[b] if rank == 0 else None, dst=0, async_op=True)
 
     last = [0]
 
@@ -546,10 +904,11 @@ def main():
         sync()
         tot["rays"] = tot["rays"] / nstat * args.steps
     if n > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = "cpu" if (dry or rehearse) else dev
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        r = torch.tensor([float(tot["rays"])], dtype=torch.float64, device=dev)
+        r = torch.tensor([float(tot["rays"])], dtype=torch.float64, device=cdev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_rays = float(r.item())
     else:
@@ -584,85 +943,117 @@ def main():
                                       f"{resx}x{resy}, primary + shadow rays only, reflect=refract=0",
                           "frame": [resx, resy], "rays_per_step": total_rays / args.steps,
                           "parallelism": f"tiles{TILE}x{TILE} round-robin over {n} GPU(s), scene replicated, gather to rank 0"}}
+        if rehearse:
+            out["config"]["rehearsal"] = "gloo backend, every rank on GPU 0, collectives staged through the host: NOT a measurement"
         if n > 1:
             # the frame rank 0 assembled from the ranks' last gather against the same frame rendered whole on rank 0
             pw = host.default_params("hw4", primary_only=1)
             abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(pw), frame.data_ptr(), None, None, sp))
             torch.cuda.synchronize()
             out["config"]["assembled_frame_equals_one_gpu_frame"] = bool(torch.equal(final.view(-1), frame))
-        # roofline of the dominant kernel (k_trace_closest): algorithmic bytes / HIP-event time
-        alg = algorithmic_bytes_per_ray(gs, cam, host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank,
-                                                                      tile_nranks=n), sp)
+        else:
+            # parity: the 4K frame's primary hit ids against the reference's own digest (tests/golden/monkey4k_hits_digest.npz,
+            # made by oracle/gen_golden.py from the unmodified SimpleMeshRayTrace through ID-colour materials)
+            try:
+                g = np.load(os.path.join(ROOT, "tests", "golden", "monkey4k_hits_digest.npz"))
+                ids = hit_ids.cpu().numpy()
+                dig = hashlib.sha256(np.ascontiguousarray(ids.reshape(resy, resx).T.astype("<i4")).tobytes()).hexdigest()   # the reference's x-major order
+                want_dig = str(g["sha256_ids_xy"].item())
+                out["parity"] = dict(frame=[resx, resy], hit_id_sha256=dig, reference_sha256=want_dig,
+                                     parity_ok=bool(want_dig is not None and dig == want_dig))
+            except Exception as e:
+                out["parity"] = dict(error=f"{type(e).__name__}: {e}", parity_ok=False)
+        # roofline of the dominant kernel: counters of the committed profile, time live
+        pr = host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n)
+        stw = render_work(gs, cam, pr, sp, torch)
         launches = max(1, tot["closest_launches"])
-        rays_per_launch = tot["closest_rays"] / launches
         avg_ms = tot["closest_ms"] / launches
         fused = tot["any_launches"] == 0 and tot["shadow_rays"] > 0       # the whole frame is ONE kernel (k_primary_only)
-        shadow_per_launch = tot["shadow_rays"] / launches
-        bytes_per_launch = alg["bytes_per_ray"] * rays_per_launch + (alg["any_bytes_per_ray"] * shadow_per_launch if fused else 0.0)
-        gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        kernel = "k_primary_only" if fused else "k_trace_closest"
-        traffic = _traffic("monkey_4k." + kernel)
-        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                           "traffic": traffic, "kernel": kernel, "avg_launch_ms": avg_ms,
-                           "rays_per_launch": rays_per_launch + (shadow_per_launch if fused else 0.0),
-                           "bytes_per_ray": alg["bytes_per_ray"],
-                           "box_tests_per_ray": alg["box_tests_per_ray"], "tri_tests_per_ray": alg["tri_tests_per_ray"],
-                           "exact_tri_tests_per_ray": alg["exact_tri_tests_per_ray"],
-                           "any_hit_bytes_per_ray": alg["any_bytes_per_ray"],
-                           "any_hit_ms_per_step": tot["any_ms"] / max(1, nstat),
-                           "note": ("one fused kernel traces the primary AND the shadow rays (generate, closest hit, any hit, shade, "
-                                    "pixel): algorithmic bytes of both. " if fused else "") +
-                                   "The scene (the build's BVH over the tree triangles, DESIGN 4.1e: 41 KB of nodes per octant "
-                                   "layout + 46 KB of triangles) is cache resident: the algorithmic bytes are served by the scalar "
-                                   "cache / L2, not HBM, and the kernel is bound by vector-instruction issue (SQ counters: the "
-                                   "vector instructions alone account for the kernel time, profiles/r01_sq_monkey_4k.json); "
-                                   "see DESIGN.md"}
-        if not args.no_cpu_baseline and n == 1:      # the CPU leg is timed at N = 1 only
-            w, h = (int(x) for x in args.cpu_sample.split("x"))
-            out["cpu_baseline"] = cpu_baseline(sd, (w, h))
-            try:
-                out["cpu_baseline"]["all_cores"] = cpu_port_all_cores(sd, (w, h))
-            except Exception as e:      # a reported extra, never a reason to lose the line
-                out["cpu_baseline"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
-        if not args.no_knn and n == 1:
+        alg_c, wave_c = traversal_bytes(stw.closest_work, stw.rays_primary)
+        alg_a, wave_a = traversal_bytes(stw.any_work, stw.rays_shadow, out_bytes=1)
+        kernel = "k_primary_only" if fused else "k_trace_closest_bvh"
+        out["roofline"] = make_roofline(
+            "monkey_4k", kernel, avg_ms, (tot["closest_rays"] + (tot["shadow_rays"] if fused else 0)) / launches,
+            alg_c + (alg_a if fused else 0.0), wave_c + (wave_a if fused else 0.0),
+            box_tests_per_ray=stw.closest_work[0] / max(1, stw.rays_primary), tri_records_per_ray=stw.closest_work[1] / max(1, stw.rays_primary),
+            exact_tri_tests_per_ray=stw.closest_work[2] / max(1, stw.rays_primary),
+            shadow_box_tests_per_ray=stw.any_work[0] / max(1, stw.rays_shadow), shadow_tri_records_per_ray=stw.any_work[1] / max(1, stw.rays_shadow),
+            note=("one fused kernel traces the primary AND the shadow rays (generate, closest hit, any hit, shade, pixel). " if fused else "") +
+                 "The scene (87 KB) lives in the scalar cache / L2: HBM sees the frame that is written and little else, so the "
+                 "kernel is priced against instruction issue; see DESIGN.md 4.1d / 5")
+        if "headline" in cpu:
+            out["cpu_baseline"] = cpu["headline"]
+        if n == 1 and not args.no_knn:
             sec = {}
             for name, fn in (("knn", lambda: knn_secondary(gs, torch, args.knn_photons, args.knn_queries)),
-                             ("mesh_1m", lambda: mesh_secondary(torch, local_rank)),
+                             ("mesh_1m", lambda: mesh_secondary(torch, local_rank, cpu=cpu.get("mesh_1m"))),
                              ("drt_1m", lambda: drt_secondary(torch, local_rank)),
                              ("photon_frame", lambda: photon_frame_secondary(torch, local_rank)),
+                             # BASELINE configuration 4 at its stated size: 10 M + 1 M photons from GPU emission, 1080p
+                             ("photon_frame_full", lambda: photon_frame_secondary(torch, local_rank, 10_000_000, 1_000_000, (1920, 1080), tag="photon_frame_full")),
                              # one GPU's share of BASELINE configuration 5 (scene and photon map are replicated per GPU)
                              ("stress_mesh_10m", lambda: mesh_secondary(torch, local_rank, steps=3, nu=3162, nv=1581, tag="stress_mesh_10m")),
                              ("stress_knn_200m", lambda: knn_secondary(gs, torch, 200_000_000, args.knn_queries, steps=2, with_cpu=False))):
-                if args.only_secondary and name not in args.only_secondary.split(","):
+                if not want(name):
                     continue
-                if name.startswith("stress_") and name not in args.only_secondary.split(","):
-                    continue                      # BASELINE configuration 5's sizes: minutes of host build, on request only
                 try:
+                    t0 = time.perf_counter()
                     sec[name] = fn()
+                    log(f"{name}: {time.perf_counter() - t0:.1f} s")
                 except Exception as e:           # a secondary line must never take the headline down with it
                     sec[name] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
+    watchdog = None
     if n > 1 and not args.no_knn:
+        # the secondary lines at N > 1 contain collectives; if a rank dies inside one the others would wait for ever and the
+        # headline would be lost with them.  After 6 minutes every rank gives up: rank 0 prints the headline as it stands.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["secondary"] = {"error": "the N > 1 secondary lines did not finish within 360 s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(360.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        sec = {}
         # the metric's second half at N GPUs: every rank answers its own share of the radiance lookups (the queries
         # follow their pixels, the photon map is replicated, no exchange: SURVEY 8e), weak scaling like the frame
         try:
             r = knn_secondary(gs, torch, args.knn_photons, args.knn_queries, steps=3, with_cpu=False)
-            ms = torch.tensor([r["ms_per_step"]], dtype=torch.float64, device="cuda")
+            ms = r["ms_per_step"]
         except Exception as e:
             log(f"rank {rank}: kNN line failed: {type(e).__name__}: {e}")
-            r, ms = None, torch.tensor([float("inf")], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+            r, ms = None, float("inf")
+        ms = coll.max_float(ms, dev)
         if rank == 0:
-            if r is not None and ms.item() != float("inf"):
-                r["value"] = n * args.knn_queries / (ms.item() * 1e-3)
-                r["ms_per_step"] = ms.item(); r["n_gpus"] = n
+            if r is not None and ms != float("inf"):
+                r["value"] = n * args.knn_queries / (ms * 1e-3)
+                r["ms_per_step"] = ms; r["n_gpus"] = n; r["scaling"] = "weak"
                 r["config"]["queries"] = n * args.knn_queries
                 r["note"] = "aggregate over the ranks: each answers its own queries on its replica of the map; time = slowest rank"
-                out["secondary"] = {"knn": r}
+                sec["knn"] = r
             else:
-                out["secondary"] = {"knn": {"error": "a rank failed"}}
+                sec["knn"] = {"error": "a rank failed"}
+        # the configurations that are meant to scale, strong scaling (every rank runs them: collectives inside)
+        for name, fn in (("drt_1m_strong", lambda: drt_strong(torch, coll, rank, n, local_rank)),
+                         ("emission_sharded", lambda: emission_sharded(torch, dist, coll, rank, n, local_rank))):
+            if only and name not in only:
+                continue
+            try:
+                res = fn()
+            except Exception as e:
+                log(f"rank {rank}: {name} failed: {type(e).__name__}: {e}")
+                res = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                sec[name] = res
+        if rank == 0:
+            out["secondary"] = sec
     if n > 1:
         dist.barrier()
+        if watchdog is not None:
+            watchdog.cancel()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)

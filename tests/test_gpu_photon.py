@@ -228,3 +228,38 @@ def test_coherent_queries_share_a_walk(gscene):
     rgb = gscene.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, 100, 1.0)
     want = _oracle_irr(heap, qp, qn, 100, 1.0)
     assert _irr_equal(gscene, rgb[:500], want[:500]) and not rgb[500:].any() and not want[500:573].any()
+
+
+def test_map_image_export_import_between_scenes():
+    """one build per node (raytracer_amd/dist.py): a scene that built its map exports the device image, another scene
+    imports it (what a rank does with the image it received over RCCL) and answers queries with the same bits; the
+    receiving scene never ran the host balance."""
+    import torch
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    a_scene, b_scene = host.Scene(sd), host.Scene(sd)
+    a = _random_map(150_000, 91)
+    heap = a_scene.photonmap_build(abi.RT_PMAP_GLOBAL, a)
+    L = a_scene.L
+    n, nb = C.c_int64(0), C.c_int64(0)
+    abi.check(L.rt_photonmap_image_bytes(a_scene.h, 0, C.byref(n), C.byref(nb)))
+    assert n.value == 150_000 and nb.value > 150_000 * 64
+    img = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+    box = (C.c_float * 6)()
+    abi.check(L.rt_photonmap_export_dev(a_scene.h, 0, img.data_ptr(), nb.value, box, None))
+    torch.cuda.synchronize()
+    assert L.rt_photonmap_import_dev(b_scene.h, 0, img.data_ptr(), n.value, nb.value - 16, box, None) == abi.RT_E_INVALID   # wrong size
+    abi.check(L.rt_photonmap_import_dev(b_scene.h, 0, img.data_ptr(), n.value, nb.value, box, None))
+    del img
+    rng = np.random.default_rng(92)
+    qp = rng.uniform(-0.5, 0.5, (5000, 3)).astype(np.float32); qp[:2000, 1] = -0.5
+    qn = rng.normal(size=qp.shape).astype(np.float32)
+    for mode in ("fast", "strict"):
+        a_scene.set_knn(mode); b_scene.set_knn(mode)
+        ra = a_scene.photon_irradiance(0, qp, qn, 100, 0.3)
+        rb = b_scene.photon_irradiance(0, qp, qn, 100, 0.3)
+        assert ra.tobytes() == rb.tobytes() and np.abs(ra).max() > 0
+    ia, da, fa, _ = a_scene.photon_knn(0, qp[:500], 50, 0.3)
+    ib, db, fb, _ = b_scene.photon_knn(0, qp[:500], 50, 0.3)
+    oi, od, of, _ = _oracle_knn(heap, qp[:500], 50, 0.3)
+    assert np.array_equal(ia, ib) and np.array_equal(ib, oi) and db.tobytes() == od.tobytes() and np.array_equal(fb, of)
+    a_scene.close(); b_scene.close()

@@ -1,0 +1,27 @@
+#!/bin/bash
+# rocprofv3 on each workload of bench.py (tools/prof_target.py runs ONE workload, so a kernel name maps to one workload):
+# one --kernel-trace --stats run, then the PMC passes, each in a run of its own as the pool requires: FETCH_SIZE,
+# WRITE_SIZE, TCC hit/miss, and two SQ passes (<= 8 SQ counters each).  Output: gpurun_out/pmc/<workload>/<pass>/.
+# tools/prof_counters.py turns that into profiles/<tag>_counters.json and profiles/<tag>_kernel_stats_<workload>.txt.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+W="${1:-monkey_4k mesh_1m drt_1m knn_10m photon_frame}"
+LIMIT="${2:-300}"
+for w in $W; do
+  for pass in stats FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
+              "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+              "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
+    tag=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
+    out=gpurun_out/pmc/$w/$tag
+    rm -rf "$out"; mkdir -p "$out"
+    if [ "$pass" = stats ]; then
+      timeout -s KILL "$LIMIT" rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o r -- python3 tools/prof_target.py "$w" > "$out/stdout.txt" 2> "$out/stderr.txt"
+    else
+      timeout -s KILL "$LIMIT" rocprofv3 --pmc $pass --output-format csv -d "$out" -o r -- python3 tools/prof_target.py "$w" > "$out/stdout.txt" 2> "$out/stderr.txt"
+    fi
+    rc=$?
+    echo "$w $tag rc=$rc $(tail -n 1 "$out/stdout.txt")"
+    if [ $rc -ne 0 ]; then tail -n 5 "$out/stderr.txt"; exit $rc; fi
+  done
+done

@@ -27,7 +27,7 @@ elif what == "mesh_1m":
     print("mesh_1m", r["value"], r["roofline"]["avg_launch_ms"])
 elif what == "knn_10m":
     gs = host.Scene(bench.bench_scene())
-    r = bench.knn_secondary(gs, torch, 10_000_000, 1920 * 1080, steps=2)
+    r = bench.knn_secondary(gs, torch, 10_000_000, 1920 * 1080, steps=2, with_cpu=False)
     print("knn_10m", r["value"], r["ms_per_step"])
 elif what == "drt_1m":
     r = bench.drt_secondary(torch, 0)
