@@ -210,7 +210,11 @@ struct BvhBuilder {
             emit(right_first ? *n.l : *n.r, depth + 1, o, croot, out);
         }
         DevBvhNode& r = out[me];
-        memcpy(r.lo, n.lo, 12); memcpy(r.hi, n.hi, 12);
+        for (int k = 0; k < 3; ++k) {                                 // mirrored frame of layout o (rt_internal.h: DevBvhNode::b)
+            const bool neg = (o >> k) & 1;
+            r.b[2 * k] = neg ? -n.hi[k] : n.lo[k];
+            r.b[2 * k + 1] = neg ? -n.lo[k] : n.hi[k];
+        }
         {   // lateral_slack (trace_device.h) for |dir| in [0.999, 1.001], the rays traverse_bvh takes; 15 eps = 8.9e-7 is
             // applied as 1.0e-6
             const double g = 1.001 * (double)n.gm, d0 = 1e-6 - 4.0e-7 * g;

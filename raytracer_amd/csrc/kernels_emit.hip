@@ -117,7 +117,7 @@ k_emit_photons(DevSceneView sc, rt_emit_params e, int light, int64_t first, int6
         push(stk, sp, lane, p);
     }
     // every lane pops one pending continuation per round; the wave leaves when all stacks are empty
-    while (__ballot(sp > 0) != 0ull) {
+    while (rt_ballot(sp > 0) != 0ull) {
         bool active = sp > 0;
         Pending p;
         if (active) p = pop(stk, sp, lane);

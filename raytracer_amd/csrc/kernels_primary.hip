@@ -22,7 +22,7 @@ k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(i & 63);
     const bool slot = i < ntiles * 64;
-    if (__ballot(slot) == 0ull) return;                          // a wave beyond the last micro-tile
+    if (rt_ballot(slot) == 0ull) return;                          // a wave beyond the last micro-tile
     const int t = slot ? (tiles ? tiles[i >> 6] : (int)(i >> 6)) : 0;
     const int tw = (cam.resx + 7) >> 3;
     const int x = (t % tw) * 8 + (lane & 7), y = (t / tw) * 8 + (lane >> 3);
@@ -40,7 +40,7 @@ k_primary_only(DevSceneView sc, rt_camera cam, const int32_t* __restrict__ tiles
 
     // per-wave counts of rays and hits (rt_stats): no barrier, the waves of a block finish at different times
     {
-        const unsigned long long m0 = __ballot(inside), m1 = __ballot(hit);
+        const unsigned long long m0 = rt_ballot(inside), m1 = rt_ballot(hit);
         if (lane == 0 && wave_pairs != nullptr) { wave_pairs[2 * (i >> 6)] = (unsigned)__builtin_popcountll(m0); wave_pairs[2 * (i >> 6) + 1] = (unsigned)__builtin_popcountll(m1); }
     }
 

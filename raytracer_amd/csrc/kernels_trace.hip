@@ -120,7 +120,7 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
     wk.bc = BvhConsts{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
     for (;;) {
-        const unsigned long long need = __ballot(!have && more);
+        const unsigned long long need = rt_ballot(!have && more);
         if (need != 0ull) {
             const int first = __builtin_ctzll(need);
             unsigned long long base = 0;
@@ -148,13 +148,13 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
             // primitives outside the trees (spheres), for the rays just taken.  The reference tests them after the trees
             // and keeps an equal-len tree hit; testing them first gives the same answer because a tree hit of equal len
             // still replaces them (their rank stays 0x7fffffff), and their len already bounds the walk.
-            if (sc.nloose > 0 && __ballot(fresh) != 0ull) {
+            if (sc.nloose > 0 && rt_ballot(fresh) != 0ull) {
                 loose_prims<ANY>(sc, wk.r, fresh, eps_f, wk.far_limit, use_tmax, best, occ);
                 if (ANY && fresh && occ) wk.i = sc.nbvh;             // occluded already: nothing to walk
                 fresh = false;
             }
         }
-        if (__ballot(have) == 0ull) { if (__ballot(more) == 0ull) break; continue; }
+        if (rt_ballot(have) == 0ull) { if (rt_ballot(more) == 0ull) break; continue; }
         int t0, t1;
         bvh_lane_next_leaf<ANY>(sc, wk, have, best, t0, t1);
         if (have && t0 < t1) { if (bvh_lane_leaf<ANY>(sc, wk, t0, t1, eps_f, use_tmax, best)) occ = true; }

@@ -62,7 +62,12 @@ static_assert(sizeof(DevLeafGroup) == 64, "DevLeafGroup must be 64 bytes");
 // pointers, eight layouts like the reference nodes.  A node carries what the group test of 4.1b needs to inflate its
 // box soundly: the largest |e1||e2| and the smallest |e1 x e2| of its triangles, and (small subtrees) their normal cone.
 struct DevBvhNode {         // 64 B
-    float lo[3], hi[3];     // bounding box of the subtree's triangles
+    float b[6];             // bounding box of the subtree's triangles as {near_x, far_x, near_y, far_y, near_z, far_z} in the
+                            // MIRRORED frame of the node's octant layout o: an axis whose bit is set in o (rays travel towards
+                            // -axis) is negated, so near = -hi, far = -lo there and near <= far on every axis.  A ray of that
+                            // octant, mirrored the same way, has only positive direction components: its slab entry is the
+                            // largest `near` parameter and its exit the smallest `far` one, no per-axis min / max; the pairs
+                            // (near, far) feed packed f32 instructions.  Layout 0 is the unmirrored box (lo, hi interleaved).
     float slack;            // box inflation per unit of reach for a unit-length ray when nothing bounds |det| but the
                             // reference's cut-off (trace_device.h: lateral_slack with |dir| <= 1.001), + 2e-5 for the slabs
     float cone_k;           // with the cone: the inflation per unit reach is cone_k / cos(angle + cone), if smaller

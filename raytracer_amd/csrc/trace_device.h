@@ -22,6 +22,10 @@ struct Rayf { float ox, oy, oz, dx, dy, dz; };
 
 __device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 
+// wave-wide vote on a bool: the lane mask of the comparison itself (HIP's __ballot takes an int, so the bool is first
+// materialised as 0 / 1 in a vector register and compared again)
+__device__ __forceinline__ unsigned long long rt_ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 // KDNode::HitTest, hw4.cpp:281-328.  lo/hi are center -/+ extend/2.0f.
 __device__ __forceinline__ bool box_test_b(const float* __restrict__ lo, const float* __restrict__ hi, const Rayf& r) {
     float tmin = (lo[0] - r.ox) / r.dx;
@@ -134,7 +138,7 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
     const int nn = sc.nnodes;
     int i = 0;
     while (i < nn) {
-        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
+        if (ANY) { if (rt_ballot(fail != RT_DEAD) == 0ull) break; }
         const DevNode nd = sc.nodes[i];                 // wave-uniform address
         const int depth = nd.meta & 0xff;
         if (fail >= depth) fail = RT_ALIVE;             // left the subtree this lane had failed in
@@ -145,7 +149,7 @@ __device__ __forceinline__ void traverse(const DevSceneView& sc, const Rayf& r, 
             hit = box_test(nd, r);
             if (!hit) fail = depth;
         }
-        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
+        if (rt_ballot(hit) == 0ull) { i = nd.skip; continue; }
         if (nd.meta & 0x100) {
             for (int k = 0; k < nd.leaf_count; ++k) {
                 const DevLeafTri* __restrict__ t = sc.leaf_tris + (nd.leaf_first + k);   // wave-uniform
@@ -247,7 +251,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
     int fail = valid ? RT_ALIVE : RT_DEAD;
     const RayAux aux = ray_aux(r);
     // the wave's layout: octant of its first valid ray (any choice is correct, this one is fastest)
-    const unsigned long long vm = __ballot(valid);
+    const unsigned long long vm = rt_ballot(valid);
     if (vm == 0ull) return;
     const int oct_l = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
     const int oct = __builtin_amdgcn_readlane(oct_l, __builtin_ctzll(vm));
@@ -256,7 +260,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
     const int nn = sc.nnodes;
     int i = 0;
     while (i < nn) {
-        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
+        if (ANY) { if (rt_ballot(fail != RT_DEAD) == 0ull) break; }
         const DevNode nd = nodes[i];                    // wave-uniform address
         const int depth = nd.meta & 0xff;
         if (fail >= depth) fail = RT_ALIVE;
@@ -277,7 +281,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
             }
             if (!hit) fail = depth;
         }
-        if (__ballot(hit) == 0ull) { i = nd.skip; continue; }
+        if (rt_ballot(hit) == 0ull) { i = nd.skip; continue; }
         if (nd.meta & 0x100) {
             // lateral slack of this leaf for the lane: how far outside a triangle's true extent a ray may pass and
             // still be accepted by the reference's rounded u / v tests, per unit of group factor
@@ -305,7 +309,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
                     // the box is already inflated by sl on every side: the interval test needs no further slack
                     if (ex < en || ex * aux.dlen < 0.0f || en * aux.dlen > limit) ghit = false;
                 }
-                if (__ballot(ghit) == 0ull) continue;
+                if (rt_ballot(ghit) == 0ull) continue;
                 const int t0 = nd.leaf_first + g * RT_GROUP;
                 const int t1 = (t0 + RT_GROUP < nd.leaf_first + nd.leaf_count) ? t0 + RT_GROUP : nd.leaf_first + nd.leaf_count;
                 for (int ti = t0; ti < t1; ++ti) {
@@ -325,7 +329,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
                     const float du = tx * pvx + ty * pvy + tz * pvz;
                     const float ua = du * ri;
                     cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
-                    if (__ballot(cand) == 0ull) continue;
+                    if (rt_ballot(cand) == 0ull) continue;
                     const float qx = ty * e1z - tz * e1y;
                     const float qy = tz * e1x - tx * e1z;
                     const float qz = tx * e1y - ty * e1x;
@@ -333,7 +337,7 @@ __device__ __forceinline__ void traverse_fast(const DevSceneView& sc, const Rayf
                     const float dt = e2x * qx + e2y * qy + e2z * qz;
                     const float va = dv * ri, ta = dt * ri;
                     cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
-                    if (__ballot(cand) == 0ull) continue;
+                    if (rt_ballot(cand) == 0ull) continue;
                     // --- the reference's exact sequence for the survivors (hw4.cpp:211-230) ---
                     if (cand) {
                         if (COUNT) w->exact += 1;
@@ -436,7 +440,7 @@ __device__ __forceinline__ void traverse_lane(const DevSceneView& sc, const Rayf
                 }
             }
         }
-        if (__ballot(t0 < t1) == 0ull) break;
+        if (rt_ballot(t0 < t1) == 0ull) break;
         for (int ti = t0; ti < t1; ++ti) {
             const DevLeafTri* __restrict__ t = sc.leaf_tris + ti;
             if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
@@ -513,15 +517,18 @@ __device__ __forceinline__ int reachable_rank(const DevSceneView& sc, int tref, 
 }
 
 // per-ray constants of the BVH walk
+typedef float rt_v2f __attribute__((ext_vector_type(2)));
 struct BvhConsts {
-    float rx, ry, rz, dlen, rlen;
-    float px, py, pz;      // -orig * (1/d) per axis
+    float rx, ry, rz;      // 1/d per axis in the MIRRORED frame of the layout walked (axis negated where the layout's bit is set)
+    float dlen, rlen;
+    float px, py, pz;      // -orig * (1/d) per axis (the same in either frame)
     float d0;              // reach of a node = d0 + its rho >= |orig - v0| + 0.44 (|e1| + |e2|) for every triangle below it
     float sl0;             // the constant part of the inflation
 };
-__device__ __forceinline__ BvhConsts bvh_consts(const DevSceneView& sc, const Rayf& r, const RayAux& aux, float root_rho) {
+__device__ __forceinline__ BvhConsts bvh_consts(const DevSceneView& sc, const Rayf& r, const RayAux& aux, float root_rho, int oct) {
     BvhConsts b;
-    b.rx = aux.rx; b.ry = aux.ry; b.rz = aux.rz; b.dlen = aux.dlen; b.rlen = aux.rlen;
+    b.rx = (oct & 1) ? -aux.rx : aux.rx; b.ry = (oct & 2) ? -aux.ry : aux.ry; b.rz = (oct & 4) ? -aux.rz : aux.rz;
+    b.dlen = aux.dlen; b.rlen = aux.rlen;
     const float oabs = __builtin_fabsf(r.ox) + __builtin_fabsf(r.oy) + __builtin_fabsf(r.oz);
     const float cx = sc.bvh_root_centre[0] - r.ox, cy = sc.bvh_root_centre[1] - r.oy, cz = sc.bvh_root_centre[2] - r.oz;
     b.d0 = 1.001f * sqrt_rn(cx * cx + cy * cy + cz * cz) + 1e-6f * oabs + 1e-6f;
@@ -532,7 +539,12 @@ __device__ __forceinline__ BvhConsts bvh_consts(const DevSceneView& sc, const Ra
     return b;
 }
 // does the ray pass the node's box, inflated by the slack of the triangles below it, in front of the origin and not
-// beyond `limit`?
+// beyond `limit`?  The box is stored in the mirrored frame of its layout (rt_internal.h: DevBvhNode::b) and the ray's
+// reciprocals are mirrored alike (bvh_consts), so both near planes, both far planes are one packed instruction each.
+// UNI: every direction component is positive in that frame (the ray's octant is the layout's): entry = the largest
+// near parameter, exit = the smallest far one.  Otherwise the per-axis min / max sort them, as the reference's
+// HitTest does.  Same values either way: (-hi - sl) * (-1/d) is (hi + sl) * (1/d) exactly.
+template <bool UNI>
 __device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r, const BvhConsts& b, float limit) {
     float lat = nd.slack;
     if (nd.meta & 0x200) {
@@ -542,33 +554,37 @@ __device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r,
         if (lb > 0.0f) lat = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
     }
     const float sl = __builtin_fmaf(lat, b.d0 + nd.rho, b.sl0);
-    const float x0 = __builtin_fmaf(nd.lo[0] - sl, b.rx, b.px), x1 = __builtin_fmaf(nd.hi[0] + sl, b.rx, b.px);
-    const float y0 = __builtin_fmaf(nd.lo[1] - sl, b.ry, b.py), y1 = __builtin_fmaf(nd.hi[1] + sl, b.ry, b.py);
-    const float z0 = __builtin_fmaf(nd.lo[2] - sl, b.rz, b.pz), z1 = __builtin_fmaf(nd.hi[2] + sl, b.rz, b.pz);
-    const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-    const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-    return !(ex < en || ex * b.dlen < 0.0f || en * b.dlen > limit);
+    const rt_v2f s2 = {-sl, sl};
+    rt_v2f x = {nd.b[0], nd.b[1]}, y = {nd.b[2], nd.b[3]}, z = {nd.b[4], nd.b[5]};
+    x = x + s2; y = y + s2; z = z + s2;
+    // (the six multiply-adds stay single: packed, each of rx .. pz would occupy a register PAIR, which spills)
+    x.x = __builtin_fmaf(x.x, b.rx, b.px); x.y = __builtin_fmaf(x.y, b.rx, b.px);
+    y.x = __builtin_fmaf(y.x, b.ry, b.py); y.y = __builtin_fmaf(y.y, b.ry, b.py);
+    z.x = __builtin_fmaf(z.x, b.rz, b.pz); z.y = __builtin_fmaf(z.y, b.rz, b.pz);
+    float en, ex;
+    if (UNI) {
+        en = __builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x);
+        ex = __builtin_fminf(__builtin_fminf(x.y, y.y), z.y);
+    } else {
+        en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
+        ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
+    }
+    return !(ex < en || ex < 0.0f || en * b.dlen > limit);
 }
 __device__ __forceinline__ bool bvh_fit(const RayAux& aux) { return aux.plain && aux.dlen > 0.999f && aux.dlen < 1.001f; }
 
-template <bool ANY, bool COUNT = false>
-__device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf& r, bool valid,
-                                             float eps_f, float tmax, bool use_tmax,
-                                             Closest& best, bool& occluded, Work* w = nullptr) {
-    const RayAux aux = ray_aux(r);
-    if (__ballot(valid && !bvh_fit(aux)) != 0ull || sc.nbvh == 0) { traverse_fast<ANY, COUNT>(sc, r, valid, eps_f, tmax, use_tmax, best, occluded, w); return; }
+template <bool ANY, bool COUNT, bool UNI>
+__device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const Rayf& r, bool valid, const RayAux& aux, int oct,
+                                                  float eps_f, float tmax, bool use_tmax,
+                                                  Closest& best, bool& occluded, Work* w) {
     int fail = valid ? RT_ALIVE : RT_DEAD;
-    const unsigned long long vm = __ballot(valid);
-    if (vm == 0ull) return;
-    const int oct_l = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
-    const int oct = __builtin_amdgcn_readlane(oct_l, __builtin_ctzll(vm));
     const DevBvhNode* __restrict__ nodes = sc.bvh_oct[oct];
     const float far_limit = ANY ? (use_tmax ? tmax : 1e9f) : 0.f;
     const int nn = sc.nbvh;
-    const BvhConsts bc = bvh_consts(sc, r, aux, sc.bvh_root_rho);
+    const BvhConsts bc = bvh_consts(sc, r, aux, sc.bvh_root_rho, oct);
     int i = 0;
     while (i < nn) {
-        if (ANY) { if (__ballot(fail != RT_DEAD) == 0ull) break; }
+        if (ANY) { if (rt_ballot(fail != RT_DEAD) == 0ull) break; }
         const DevBvhNode nd = nodes[i];                   // wave-uniform address
         const int depth = nd.meta & 0xff;
         if (fail >= depth) fail = RT_ALIVE;
@@ -576,11 +592,11 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
         if (COUNT) w->fetch += 1;
         if (fail == RT_ALIVE) {
             if (COUNT) w->box += 1;
-            hit = bvh_box_hit(nd, r, bc, ANY ? far_limit : best.len);
+            hit = bvh_box_hit<UNI>(nd, r, bc, ANY ? far_limit : best.len);
             if (!hit) fail = depth;
         }
         const bool leaf = (nd.meta & 0x100) != 0;
-        if (__ballot(hit) == 0ull) { i = leaf ? i + 1 : nd.skip; continue; }
+        if (rt_ballot(hit) == 0ull) { i = leaf ? i + 1 : nd.skip; continue; }
         if (leaf) {
             const int t0 = nd.skip, t1 = nd.skip + (nd.meta >> 16);
             for (int ti = t0; ti < t1; ++ti) {
@@ -599,7 +615,7 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
                 const float du = tx * pvx + ty * pvy + tz * pvz;
                 const float ua = du * ri;
                 cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
-                if (__ballot(cand) == 0ull) continue;
+                if (rt_ballot(cand) == 0ull) continue;
                 const float qx = ty * e1z - tz * e1y;
                 const float qy = tz * e1x - tx * e1z;
                 const float qz = tx * e1y - ty * e1x;
@@ -607,7 +623,7 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
                 const float dt = e2x * qx + e2y * qy + e2z * qz;
                 const float va = dv * ri, ta = dt * ri;
                 cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
-                if (__ballot(cand) == 0ull) continue;
+                if (rt_ballot(cand) == 0ull) continue;
                 if (cand) {                                                          // hw4.cpp:211-230: the same values, tested together
                     if (COUNT) w->exact += 1;
                     const float detInv = 1.0f / det;
@@ -635,6 +651,22 @@ __device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf&
     }
 }
 
+template <bool ANY, bool COUNT = false>
+__device__ __forceinline__ void traverse_bvh(const DevSceneView& sc, const Rayf& r, bool valid,
+                                             float eps_f, float tmax, bool use_tmax,
+                                             Closest& best, bool& occluded, Work* w = nullptr) {
+    const RayAux aux = ray_aux(r);
+    if (rt_ballot(valid && !bvh_fit(aux)) != 0ull || sc.nbvh == 0) { traverse_fast<ANY, COUNT>(sc, r, valid, eps_f, tmax, use_tmax, best, occluded, w); return; }
+    const unsigned long long vm = rt_ballot(valid);
+    if (vm == 0ull) return;
+    // the wave's layout: octant of its first valid ray (any choice is correct, this one is fastest); when every valid ray
+    // is of that octant -- a tile of primary rays, shadow rays towards one light -- the box test needs no min / max
+    const int oct_l = (r.dx < 0.f ? 1 : 0) | (r.dy < 0.f ? 2 : 0) | (r.dz < 0.f ? 4 : 0);
+    const int oct = __builtin_amdgcn_readlane(oct_l, __builtin_ctzll(vm));
+    if (rt_ballot(valid && oct_l != oct) == 0ull) traverse_bvh_walk<ANY, COUNT, true>(sc, r, valid, aux, oct, eps_f, tmax, use_tmax, best, occluded, w);
+    else traverse_bvh_walk<ANY, COUNT, false>(sc, r, valid, aux, oct, eps_f, tmax, use_tmax, best, occluded, w);
+}
+
 // ---------------------------------------------------------------------------
 // BVH walk PER LANE, for rays that are not coherent across a wave: the state of one ray's walk, advanced in
 // the "while-while" shape of traverse_lane -- to the next leaf whose box the ray passes, then through its triangles.
@@ -652,7 +684,7 @@ __device__ __forceinline__ void bvh_lane_start(const DevSceneView& sc, const Ray
 #pragma unroll
     for (int o = 1; o < 8; ++o) if ((oct & sc.lane_layout_mask) == o) nodes = sc.bvh_oct[o];
     wk.r = r; wk.nodes = nodes; wk.i = 0; wk.far_limit = far_limit;
-    wk.bc = bvh_consts(sc, r, aux, sc.bvh_root_rho);
+    wk.bc = bvh_consts(sc, r, aux, sc.bvh_root_rho, oct & sc.lane_layout_mask);
 }
 // advances the lane (if `on`) to its next leaf; returns its triangle range
 template <bool ANY>
@@ -662,7 +694,7 @@ __device__ __forceinline__ void bvh_lane_next_leaf(const DevSceneView& sc, BvhLa
     while (on && t0 == t1 && wk.i < nn) {
         const DevBvhNode nd = wk.nodes[wk.i];
         const bool leaf = (nd.meta & 0x100) != 0;
-        const bool hit = bvh_box_hit(nd, wk.r, wk.bc, ANY ? wk.far_limit : best.len);
+        const bool hit = bvh_box_hit<false>(nd, wk.r, wk.bc, ANY ? wk.far_limit : best.len);
         if (!hit) wk.i = leaf ? wk.i + 1 : nd.skip;
         else {
             wk.i = wk.i + 1;
@@ -725,7 +757,7 @@ __device__ __forceinline__ void loose_prims(const DevSceneView& sc, const Rayf& 
                                             Closest& best, bool& occluded, Work* w = nullptr) {
     bool live = valid && !(ANY && occluded);
     for (int k = 0; k < sc.nloose; ++k) {
-        if (ANY) { if (__ballot(live) == 0ull) break; }
+        if (ANY) { if (rt_ballot(live) == 0ull) break; }
         const DevLoose* __restrict__ l = sc.loose + k;                              // wave-uniform
         const int flags = l->flags;
         if (ANY && use_tmax && (flags & RT_PF_SKIP_SHADOW)) continue;
