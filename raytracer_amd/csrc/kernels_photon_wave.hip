@@ -145,6 +145,8 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     const DevPhotonPos* __restrict__ pp = ph + 2 * (n + 1);                // second heap: positions [n+2], powers [n+1]
     const DevPhotonPow* __restrict__ pq = reinterpret_cast<const DevPhotonPow*>(pp + (n + 2));
     const float4* __restrict__ bx = reinterpret_cast<const float4*>(pq + (n + 1));   // corners 2i, 2i+1 of node i's sub-heap box
+    // per-lane walk: node i as ONE 64-byte line {pos, packed, box of the left child's sub-heap, box of the right child's}
+    const float4* __restrict__ nodes64 = reinterpret_cast<const float4*>(ph) + rt_photon_nodes64_offset(n);
     const unsigned un = (unsigned)n, nb = (unsigned)(n / 2);               // nodes 1..nb have a child
     const float r0 = maxDist * maxDist;                                    // np.dist2[0], photon.cpp:405
     const int INF_BITS = 0x7f800000;
@@ -157,44 +159,59 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     // seen.  For queries whose neighbourhoods do not overlap (a dense map under sparse queries) the union is 64 walks
     // long, and every photon on it costs the whole wave a list insertion; per lane, one insertion step serves 64
     // different photons.  The price: per-lane record fetches instead of wave-uniform ones.
-    __shared__ unsigned lane_stack[LANE ? 32 * 64 : 1];
-    auto child_dist = [&](unsigned c) -> float {                           // lower bound of dist2 over the sub-heap of c
-        if (c <= nb) return w_boxdist(bx[2 * c], bx[2 * c + 1], qx, qy, qz);
-        return w_dist2(*reinterpret_cast<const float4*>(pp + c), qx, qy, qz);   // no children: the photon itself
+    // A step of a lane = one line: the node's photon and the boxes of both children's sub-heaps come together, so the
+    // children are accepted or pruned without touching their own lines; a child that has no children is a photon -- its
+    // "box" is its position and the box distance its dist2, bit for bit -- and is visited right there.  The deferred
+    // (farther) child of a node needs no stack entry of its own: every pending sibling lies on the current path, so a bit
+    // per depth and the sibling's box distance per depth (LDS) are enough; the sibling at depth d is (i >> (depth(i) - d)) ^ 1.
+    __shared__ float lane_stack[LANE ? 32 * 64 : 1];
+    auto boxdist6 = [&](float lx, float ly, float lz, float hx, float hy, float hz) -> float {      // w_boxdist on loose floats
+        const float dx = __builtin_fmaxf(__builtin_fmaxf(lx - qx, qx - hx), 0.0f);
+        const float dy = __builtin_fmaxf(__builtin_fmaxf(ly - qy, qy - hy), 0.0f);
+        const float dz = __builtin_fmaxf(__builtin_fmaxf(lz - qz, qz - hz), 0.0f);
+        float d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        return d;
     };
+    // visit(d2, idx, packed, own, on): one photon per lane; packed carries RT_PH_UNREACHABLE, and theta / phi when `own`
     auto lane_walk = [&](bool start, auto&& bound, auto&& visit, unsigned& steps) {
-        unsigned i = start ? 1u : 0u;
-        int sp = 0;
+        unsigned i = start ? 1u : 0u, last = 1u, pending = 0u;
         while (__ballot(i != 0u) != 0ull) {
             ++steps;
             const bool on = i != 0u;
             if (dbg) d_lanes += (unsigned)__popcll(__ballot(on));
-            float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (on) rec = *reinterpret_cast<const float4*>(pp + i);
-            visit(rec, i, on);
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
+            if (on) { const float4* __restrict__ np = nodes64 + 4 * (size_t)i; q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; last = i; }
+            const unsigned pk = (unsigned)__float_as_int(q0.w);
+            visit(w_dist2(q0, qx, qy, qz), i, pk, true, on);
+            const unsigned c0 = 2u * i;
+            const bool has_l = on && c0 <= un, has_r = on && c0 + 1u <= un;
+            const float dl = boxdist6(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y), dr = boxdist6(q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
+            const bool leaf_l = has_l && c0 > nb, leaf_r = has_r && c0 + 1u > nb;
+            if (__ballot(leaf_l) != 0ull) visit(dl, c0, (pk & 8u) ? RT_PH_UNREACHABLE : 0u, false, leaf_l);
+            if (__ballot(leaf_r) != 0ull) visit(dr, c0 + 1u, (pk & 16u) ? RT_PH_UNREACHABLE : 0u, false, leaf_r);
             unsigned next = 0u;
             if (on) {
-                const unsigned c0 = 2u * i;
-                if (c0 <= un) {
-                    const bool has_r = c0 + 1u <= un;
-                    const float dl = child_dist(c0), dr = has_r ? child_dist(c0 + 1u) : 0.f;
-                    const float bd = bound();
-                    const bool wl = dl <= bd, wr = has_r && dr <= bd;
-                    if (wl && wr) {
-                        const bool left_first = dl <= dr;
-                        lane_stack[sp * 64 + lane] = left_first ? c0 + 1u : c0; ++sp;
-                        next = left_first ? c0 : c0 + 1u;
-                    } else if (wl) next = c0;
-                    else if (wr) next = c0 + 1u;
-                }
-                while (next == 0u && sp > 0) {                             // the nearest deferred child the lane still wants
-                    --sp;
-                    const unsigned c = lane_stack[sp * 64 + lane];
-                    if (child_dist(c) <= bound()) next = c;
+                const float bd = bound();
+                const bool wl = has_l && !leaf_l && dl <= bd, wr = has_r && !leaf_r && dr <= bd;
+                const int di = 31 - __builtin_clz(i);                      // depth of i (root 0)
+                if (wl && wr) {
+                    const bool left_first = dl <= dr;
+                    lane_stack[(di + 1) * 64 + lane] = left_first ? dr : dl;
+                    pending |= 1u << (di + 1);
+                    next = left_first ? c0 : c0 + 1u;
+                } else if (wl) next = c0;
+                else if (wr) next = c0 + 1u;
+                while (next == 0u && pending != 0u) {                      // the deepest deferred sibling the lane still wants
+                    const int d = 31 - __builtin_clz(pending);
+                    pending &= ~(1u << d);
+                    if (lane_stack[d * 64 + lane] <= bound()) next = (i >> (di - d)) ^ 1u;
                 }
             }
             i = next;
         }
+        (void)last;
     };
 
     // ---- phase 2: the k+1 smallest dist2 of S per lane ---------------------------------------------------------
@@ -247,7 +264,17 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
             }
         };
         if (LANE) {
-            lane_walk(live, [&]() { return tau; }, [&](const float4& r4, unsigned, bool on) { visit(r4, on); }, d_v2);
+            lane_walk(live, [&]() { return tau; },
+                      [&](float d2, unsigned, unsigned pk, bool, bool al) {
+                          const bool cand = al && d2 <= tau && d2 < r0 && !(pk & RT_PH_UNREACHABLE);
+                          if (__ballot(cand) != 0ull) {
+                              ++d_c2;
+                              cnt += cand ? 1 : 0;
+                              w_insert<KMAX>(reg, cand ? __float_as_int(d2) : INF_BITS);
+                              const float far = __int_as_float(reg[KMAX - 1]);
+                              tau = tau < far ? tau : far;
+                          }
+                      }, d_v2);
         } else {
         int fail = live ? W_ALIVE : W_DEAD;
         unsigned i = 1, pending = 0;
@@ -382,7 +409,23 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
             }
         };
         if (LANE) {
-            lane_walk(summing, [&]() { return T; }, visit, d_v3);
+            lane_walk(summing, [&]() { return T; },
+                      [&](float d2, unsigned idx, unsigned pk, bool own, bool al) {
+                          bool member = al && d2 <= T && d2 < r0 && !(pk & RT_PH_UNREACHABLE);
+                          if (__ballot(member) != 0ull) {
+                              ++d_m3;
+                              float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                              if (member) {
+                                  w4 = *reinterpret_cast<const float4*>(pq + idx);      // power + the reference's slot
+                                  if (!own) pk = pp[idx].packed;                         // a child visited at its parent: theta / phi
+                              }
+                              member = member && __float_as_int(w4.w) != E;
+                              members += member ? 1 : 0;
+                              const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
+                              const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
+                              if (member && (dx * nx + dy * ny + dz * nz) < 0.0f) { r += w4.x; g += w4.y; b += w4.z; }
+                          }
+                      }, d_v3);
         } else {
         int fail = summing ? W_ALIVE : W_DEAD;
         unsigned i = 1, pending = 0;

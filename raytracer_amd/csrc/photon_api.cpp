@@ -44,7 +44,7 @@ int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
     std::vector<int32_t> src; std::vector<int8_t> pplane;   // [2 (n/2 + 2)] box corners
     const size_t nb = (size_t)n / 2;                // nodes of the second heap that have a child
     try {
-        dev.resize(4 * ((size_t)n + 1) + 1 + 2 * (nb + 2));
+        dev.resize(rt_photon_image_records(n));
         rt_photon_product_order(heap, n, src, pplane);
     } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
     memset(dev.data(), 0, sizeof(DevPhotonPos));
@@ -86,6 +86,25 @@ int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
                 }
             memcpy(bx[2 * i].pos, lo, 12); memcpy(bx[2 * i + 1].pos, hi, 12);
         }
+        // the per-lane walk's 64-byte node records (rt_internal.h): own photon + both children's sub-heap boxes
+        float* nd = reinterpret_cast<float*>(dev.data() + rt_photon_nodes64_offset(n));
+        memset(nd, 0, 64);
+        for (int64_t i = 1; i <= n; ++i) {
+            float* o = nd + 16 * (size_t)i;
+            memcpy(o, pp[i].pos, 12);
+            uint32_t pk = pp[i].packed & ~(8u | 16u);
+            for (int side = 0; side < 2; ++side) {
+                const int64_t c = 2 * i + side;
+                float* b = o + 4 + 6 * side;
+                if (c > n) { for (int a = 0; a < 6; ++a) b[a] = 0.f; continue; }
+                if (c <= (int64_t)nb) { memcpy(b, bx[2 * c].pos, 12); memcpy(b + 3, bx[2 * c + 1].pos, 12); }
+                else {
+                    memcpy(b, pp[c].pos, 12); memcpy(b + 3, pp[c].pos, 12);
+                    if (pp[c].packed & RT_PH_UNREACHABLE) pk |= side ? 16u : 8u;
+                }
+            }
+            memcpy(o + 3, &pk, 4);
+        }
     }
     hipError_t e = hipMalloc((void**)&m.d_photons, dev.size() * sizeof(DevPhotonPos));
     if (e != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(photon map %zu B): %s", dev.size() * sizeof(DevPhotonPos), hipGetErrorString(e));
@@ -121,7 +140,7 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, fl
 }
 
 // ---- one build per node: the device image of a map, copied between ranks' GPUs ---------------------------------------
-static size_t image_records(int64_t n) { return 4 * ((size_t)n + 1) + 1 + 2 * ((size_t)n / 2 + 2); }      // as upload_heap lays it out
+static size_t image_records(int64_t n) { return rt_photon_image_records(n); }      // as upload_heap lays it out
 
 int rt_photonmap_image_bytes(rt_scene* s, int which, int64_t* nphotons, int64_t* bytes) {
     if (!s || which < 0 || which > 1 || !nphotons || !bytes) return rt_fail(RT_E_INVALID, "rt_photonmap_image_bytes: bad argument");

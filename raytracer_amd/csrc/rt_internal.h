@@ -112,6 +112,17 @@ static_assert(sizeof(DevPhotonPos) == 16 && sizeof(DevPhotonPow) == 16, "photon 
 // photons again in the order of rt_photon_product_order: [n+2] DevPhotonPos (one padding record: both children are
 // fetched together), [n+1] DevPhotonPow, and [2 (n/2 + 2)] box corners: records 2i, 2i+1 = lo, hi of the bounding box of
 // the sub-heap of node i, for the n/2 nodes that have a child
+// ... and, 64-byte aligned behind the box corners, [n+1] 64-byte node records for the per-lane walk (kernels_photon_wave.hip):
+// {pos[3], packed, box of the left child's sub-heap lo[3] hi[3], box of the right child's}; a child without children
+// contributes its position as a degenerate box, and its RT_PH_UNREACHABLE flag moves to bit 3 (left) / 4 (right) of packed.
+// Offsets in 16-byte records from the base of the allocation:
+#ifdef __HIPCC__
+#define RT_HD __host__ __device__
+#else
+#define RT_HD
+#endif
+RT_HD static inline size_t rt_photon_nodes64_offset(int64_t n) { return (4 * ((size_t)n + 1) + 1 + 2 * ((size_t)n / 2 + 2) + 3) & ~(size_t)3; }
+RT_HD static inline size_t rt_photon_image_records(int64_t n) { return rt_photon_nodes64_offset(n) + 4 * ((size_t)n + 1); }
 typedef DevPhotonPos DevPhoton;
 #define RT_PH_UNREACHABLE 4u      // second heap: the reference's LocatePhoton never reaches this photon (Q8)
 
