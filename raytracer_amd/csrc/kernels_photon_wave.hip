@@ -31,8 +31,10 @@
 #include <cstring>
 #include "rt_internal.h"
 
-// photons per query above which the per-lane walk is launched (RT_KNN_WALK overrides)
-#define RT_KNN_LANE_RATIO 3.0
+// photons per query above which the per-lane walk is launched (RT_KNN_WALK overrides).  Since the per-lane walk reads one
+// 64-byte line per step it wins at every density measured (1 M photons under 11 M queries: 72.9 against 80.6 ms per
+// photon frame; 10 M under 6.7 M per launch: 5.23 against 5.52 s; 10 M under 2 M: 9.4 against 17.8 ms), so it is the default.
+#define RT_KNN_LANE_RATIO 0.0
 #define W_ALIVE 0x7fffffff
 #define W_DEAD  (-1)
 
@@ -180,7 +182,6 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
         while (__ballot(i != 0u) != 0ull) {
             ++steps;
             const bool on = i != 0u;
-            if (dbg) d_lanes += (unsigned)__popcll(__ballot(on));
             float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
             if (on) { const float4* __restrict__ np = nodes64 + 4 * (size_t)i; q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; last = i; }
             const unsigned pk = (unsigned)__float_as_int(q0.w);
@@ -189,6 +190,7 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
             const bool has_l = on && c0 <= un, has_r = on && c0 + 1u <= un;
             const float dl = boxdist6(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y), dr = boxdist6(q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
             const bool leaf_l = has_l && c0 > nb, leaf_r = has_r && c0 + 1u > nb;
+            if (dbg) d_lanes += (unsigned)(__popcll(__ballot(on)) + __popcll(__ballot(leaf_l)) + __popcll(__ballot(leaf_r)));   // photons examined
             if (__ballot(leaf_l) != 0ull) visit(dl, c0, (pk & 8u) ? RT_PH_UNREACHABLE : 0u, false, leaf_l);
             if (__ballot(leaf_r) != 0ull) visit(dr, c0 + 1u, (pk & 16u) ? RT_PH_UNREACHABLE : 0u, false, leaf_r);
             unsigned next = 0u;
@@ -570,7 +572,7 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
     // neighbourhoods hardly overlap and the per-lane walk wins (10 M photons under 2.07 M queries: 117 against 104 M
     // lookups/s; 200 M photons: 74 against 20; the photon frame's 1 M-photon map under denser queries: 70 against 79)
     const int walk_env = [] { const char* e = getenv("RT_KNN_WALK"); return !e ? 0 : (strcmp(e, "lane") == 0 ? 2 : (strcmp(e, "wave") == 0 ? 1 : 0)); }();
-    const bool lane_walk = walk_env ? walk_env == 2 : (double)n > RT_KNN_LANE_RATIO * (double)q;
+    const bool lane_walk = walk_env ? walk_env == 2 : (double)n >= RT_KNN_LANE_RATIO * (double)q;
     if (lane_walk) { group = 64; }
     const unsigned grid2 = (unsigned)((q + group - 1) / group);
 #define WAVE_ARGS dim3(grid2), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_redo_list, d_redo_count, perm, budget, group, d_stats
