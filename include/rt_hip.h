@@ -271,6 +271,11 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
  * lights, rt_render runs the whole frame (camera ray, closest hit, shadow rays, shading, pixel) as one kernel instead
  * of the wavefront passes: same bytes, no intermediate arrays.  0 = always the passes.  RT_FUSED_PRIMARY=0|1.       */
 #define RT_OPT_FUSED_PRIMARY 5
+/* RT_OPT_RAY_SORT (default 0: measured 3 % slower on BASELINE configuration 3; no counterpart: the reference traces one ray at a time): rt_render hands the rays of its
+ * per-lane passes (RT_OPT_LANE_DEPTH) to lanes in the order of a key -- 32^3 cell of the origin, octant of the direction,
+ * finer Morton bits -- instead of queue order (one radix sort of (key, index) pairs per pass; rays are not moved and
+ * every result lands in the ray's own slot, so frames are the same bytes either way).  RT_RAY_SORT=0|1.                */
+#define RT_OPT_RAY_SORT 6
 /* Algorithm of the radiance estimate (rt_photon_irradiance*, the photon renderer) and of rt_photon_knn_set:
  *   RT_KNN_STRICT  LocatePhoton's array / heap code statement by statement, one query per lane: np.index in the
  *                  reference's order, irradiance summed in that order (bit-identical to the reference).

@@ -210,6 +210,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.nbvh = (int32_t)flat.bvh_nodes[0].size();
     memcpy(v.bvh_root_centre, flat.bvh_root_centre, sizeof v.bvh_root_centre);
     v.bvh_root_rho = v.nbvh > 0 ? flat.bvh_nodes[0][0].rho : 0.f;
+    if (v.nbvh > 0)                                    // layout 0 is unmirrored: b = {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z}
+        for (int k = 0; k < 3; ++k) { s->bvh_lo[k] = flat.bvh_nodes[0][0].b[2 * k]; s->bvh_hi[k] = flat.bvh_nodes[0][0].b[2 * k + 1]; }
     // per-lane walks all use layout 0: with random directions the eight layouts are eight times the cache footprint,
     // which costs more than the near-first order saves (1M-triangle mesh, passes of depth >= 2: 18 % faster than with
     // the ray's own octant; RT_LANE_LAYOUT_MASK=7 restores that)
@@ -249,6 +251,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "fast") == 0) ? 1 : (strcmp(e, "lane") == 0) ? 2 : (strcmp(e, "bvh") == 0) ? 3 : s->fast;
     if (const char* e = getenv("RT_FUSED_PRIMARY")) s->fused_primary = atoi(e) != 0;
     if (const char* e = getenv("RT_LANE_DEPTH")) s->lane_depth = atoi(e) < 0 ? 0 : atoi(e);
+    if (const char* e = getenv("RT_RAY_SORT")) s->ray_sort = atoi(e) != 0;
     if (const char* e = getenv("RT_KNN")) s->knn_fast = (strcmp(e, "strict") == 0) ? 0 : 1;
 
     rt_scene_info& inf = s->info;
@@ -288,6 +291,7 @@ int rt_scene_set_option(rt_scene* s, int option, int value) {
     if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST || value == RT_TRAVERSAL_LANE || value == RT_TRAVERSAL_BVH)) { s->fast = value; return RT_OK; }
     if (option == RT_OPT_LANE_DEPTH && value >= 0) { s->lane_depth = value; return RT_OK; }
     if (option == RT_OPT_FUSED_PRIMARY && (value == 0 || value == 1)) { s->fused_primary = value; return RT_OK; }
+    if (option == RT_OPT_RAY_SORT && (value == 0 || value == 1)) { s->ray_sort = value; return RT_OK; }
     if (option == RT_OPT_KNN_STATS && (value == 0 || value == 1)) {
         DeviceGuard g(s->device);
         if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");

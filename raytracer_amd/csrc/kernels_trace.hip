@@ -22,6 +22,7 @@
 // Compile with -ffp-contract=off and correctly rounded f32 divide / sqrt.
 #include <atomic>
 #include <cstdlib>
+#include <hipcub/hipcub.hpp>
 #include "trace_device.h"
 #include "rng_device.h"
 
@@ -110,7 +111,7 @@ k_trace_any_lane(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t
 template <bool ANY>
 __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
                                           const float* __restrict__ tmax, int64_t n, float eps_f,
-                                          rt_hit* __restrict__ out, uint8_t* __restrict__ occluded) {
+                                          rt_hit* __restrict__ out, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order) {
     const int lane = threadIdx.x & 63;
     const bool use_tmax = tmax != nullptr;
     bool have = false, more = true, occ = false, fresh = false;
@@ -127,8 +128,11 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
             if (lane == first) base = atomicAdd(sc.ray_counter, (unsigned long long)__builtin_popcountll(need));
             base = __shfl(base, first, 64);
             if (!have && more) {
-                const int64_t my = (int64_t)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
-                if (my >= n) more = false;
+                // `order` (rtk_ray_order): the k-th claim takes ray order[k], so that the rays a wave holds at one time start
+                // in one region with one octant; results still go to the ray's own slot
+                const int64_t claim = (int64_t)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
+                const int64_t my = (claim < n && order != nullptr) ? (int64_t)order[claim] : claim;
+                if (claim >= n) more = false;
                 else if (active != nullptr && active[my] < 0) {
                     if (ANY) occluded[my] = 0;
                     else {
@@ -172,14 +176,14 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_trace_closest_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                          int64_t n, float eps_f, rt_hit* __restrict__ out) {
-    bvh_lanes<false>(sc, rays, active, nullptr, n, eps_f, out, nullptr);
+                          int64_t n, float eps_f, rt_hit* __restrict__ out, const int32_t* __restrict__ order) {
+    bvh_lanes<false>(sc, rays, active, nullptr, n, eps_f, out, nullptr, order);
 }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_trace_any_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                      const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
-    bvh_lanes<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded);
+                      const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order) {
+    bvh_lanes<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded, order);
 }
 
 // the build's own hierarchy instead of the reference's tree (trace_device.h: traverse_bvh)
@@ -331,6 +335,75 @@ k_generate_drt(rt_camera cam, const int32_t* __restrict__ tiles, int64_t ntiles,
 }
 
 // ---------------------------------------------------------------------------
+// Ray reordering for the per-lane kernels (north_star: "ray compaction and sorting to limit divergence").  Rays of the
+// deeper recursion levels arrive in pixel order, but their origins are scattered over the scene and their directions over
+// all octants.  A 30-bit key per ray -- the 32^3 cell of its origin, then the octant of its direction, then 12 more bits of
+// the origin's Morton code -- and one radix sort of (key, ray index) pairs give the order in which the refilling kernels
+// hand rays to lanes; nothing is moved, every result is written to the ray's own slot, so the ordered per-pixel sums
+// of k_accumulate (and with them the byte-identical frames under tiling and chunking) are untouched.
+__device__ __forceinline__ unsigned ro_spread(unsigned v) {      // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+struct RoBox { float lo[3], inv[3]; };
+extern "C" __global__ void __launch_bounds__(256)
+k_ray_keys(const rt_ray* __restrict__ rays, const int32_t* __restrict__ active, int64_t n, RoBox box,
+           unsigned* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned key = 0x3fffffffu;                                   // inactive slots last
+    if (active == nullptr || active[i] >= 0) {
+        const float* r = reinterpret_cast<const float*>(rays + i);
+        unsigned m = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float u = (r[a] - box.lo[a]) * box.inv[a];
+            u = u > 0.f ? (u < 1.f ? u : 1.f) : 0.f;              // also sends NaN to 0
+            m |= ro_spread((unsigned)(u * 511.0f)) << a;          // 27-bit Morton code, 9 bits per axis
+        }
+        const unsigned oct = (r[3] < 0.f ? 1u : 0u) | (r[4] < 0.f ? 2u : 0u) | (r[5] < 0.f ? 4u : 0u);
+        key = ((m >> 12) << 15) | (oct << 12) | (m & 0xfffu);
+    }
+    keys[i] = key; vals[i] = (int32_t)i;
+}
+
+namespace {
+struct RoWork { unsigned *keys_in, *keys_out; int32_t *vals_in, *vals_out; void* temp; size_t temp_bytes, total; };
+RoWork ro_carve(void* base, int64_t n) {
+    RoWork W;
+    size_t t1 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const unsigned*)nullptr, (unsigned*)nullptr, (const int32_t*)nullptr,
+                                             (int32_t*)nullptr, (int)n, 0, 30, (hipStream_t)nullptr);
+    char* w = (char*)base;
+    auto take = [&w](size_t bytes) { char* p = w; w += (bytes + 255) & ~(size_t)255; return (void*)p; };
+    W.keys_in = (unsigned*)take((size_t)n * 4); W.keys_out = (unsigned*)take((size_t)n * 4);
+    W.vals_in = (int32_t*)take((size_t)n * 4); W.vals_out = (int32_t*)take((size_t)n * 4);
+    W.temp_bytes = t1; W.temp = take(t1);
+    W.total = (size_t)(w - (char*)base) + 256;
+    return W;
+}
+}  // namespace
+
+size_t rtk_ray_order_workspace(int64_t n) { return n > 0 && n <= 0x7fffffff ? ro_carve(nullptr, n).total : 0; }
+
+// *order_out = n ray indices in traversal order (inside d_work), or NULL when n is too small to be worth a sort
+hipError_t rtk_ray_order(const rt_ray* d_rays, const int32_t* d_active, int64_t n, const float lo[3], const float hi[3],
+                         void* d_work, const int32_t** order_out, hipStream_t st) {
+    *order_out = nullptr;
+    if (n < 4096 || n > 0x7fffffff || !d_work) return hipSuccess;
+    const RoWork W = ro_carve(d_work, n);
+    RoBox box;
+    for (int a = 0; a < 3; ++a) { box.lo[a] = lo[a]; box.inv[a] = hi[a] > lo[a] ? 1.0f / (hi[a] - lo[a]) : 0.f; }
+    hipLaunchKernelGGL(k_ray_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rays, d_active, n, box, W.keys_in, W.vals_in);
+    size_t temp = W.temp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)n, 0, 30, st);
+    if (e != hipSuccess) return e;
+    *order_out = W.vals_out;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // host launchers (declared in rt_internal.h)
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 // the refilling per-lane BVH kernels: RT_LANE_BVH=0 keeps the reference-tree walk for every ray
@@ -352,7 +425,7 @@ static inline unsigned lanes_grid(int64_t n) {
 }
 
 hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
-                             float eps_f, int fast, rt_hit* d_out, hipStream_t st) {
+                             float eps_f, int fast, rt_hit* d_out, hipStream_t st, const int32_t* d_order) {
     if (n <= 0) return hipSuccess;
     if (fast == 3) {
         hipLaunchKernelGGL(k_trace_closest_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
@@ -364,7 +437,7 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out);
+            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
         }
         hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, lanes, d_out);
         return hipGetLastError();
@@ -374,7 +447,7 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
 }
 
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
-                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st) {
+                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st, const int32_t* d_order) {
     if (n <= 0) return hipSuccess;
     if (fast == 3) {
         hipLaunchKernelGGL(k_trace_any_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
@@ -386,7 +459,7 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
         }
         hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, lanes, d_occ);
         return hipGetLastError();

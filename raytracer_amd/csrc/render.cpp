@@ -14,9 +14,9 @@ namespace {
 
 enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
-    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE
+    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE, S_ORDER_C, S_ORDER_A
 };
-static_assert(S_QB_CODE < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_ORDER_A < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -183,15 +183,27 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             RTCHK(s->scratch(S_FLAGS, (size_t)n * 2, &flags));
             RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
         }
+        // per-lane passes: rays go to lanes in spatial / octant order (RT_OPT_RAY_SORT); the sort is timed with the pass
+        const bool sorted = pass_mode == 2 && s->ray_sort && s->view.nbvh > 0 && (s->fast == 1 || s->fast == 3);
+        const int32_t* order_c = nullptr; const int32_t* order_a = nullptr;
         RTCHK(mark());
-        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st), "k_trace_closest");
+        if (sorted) {
+            void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
+            HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st), "ray order");
+        }
+        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c), "k_trace_closest");
         RTCHK(mark());
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
                                (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, q_code, p->seed, p->light_radius, st), "k_shade_flags");
         RTCHK(mark());
-        if (L > 0)
-            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, st), "k_trace_any");
+        if (L > 0) {
+            if (sorted) {
+                void* ow; RTCHK(s->scratch(S_ORDER_A, rtk_ray_order_workspace(n * L), &ow));
+                HIPCHK(rtk_ray_order((const rt_ray*)srays, (const int32_t*)sact, n * L, s->bvh_lo, s->bvh_hi, ow, &order_a, st), "ray order");
+            }
+            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, st, order_a), "k_trace_any");
+        }
         RTCHK(mark());
         if (d_work) {
             unsigned long long* dw = d_work + (pass_mode == 2 ? 8 : 0);

@@ -3,7 +3,7 @@
 #include "rt_internal.h"
 #include <hip/hip_runtime_api.h>
 
-#define RT_NSCRATCH 32
+#define RT_NSCRATCH 40
 
 struct DeviceGuard {
     int prev, cur = -1; bool ok;
@@ -28,6 +28,9 @@ struct rt_scene {
     int knn_fast = 1;                 // radiance estimate: 1 = wave-shared kernel (default), 0 = strict list replay
     int fused_primary = 1;            // rt_render with primary_only: one kernel for the whole frame (RT_OPT_FUSED_PRIMARY)
     int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
+    int ray_sort = 0;                 // rt_render: per-lane passes hand rays to lanes in (cell, octant, Morton) order (RT_OPT_RAY_SORT;
+                                      // measured slower on BASELINE configuration 3, DESIGN 4.1c, so off by default)
+    float bvh_lo[3] = {0, 0, 0}, bvh_hi[3] = {0, 0, 0};   // box of the tree triangles (the grid of the ray-order keys)
     int fast = 3;                     // traversal: 3 = the build's own BVH (default), 1 = the reference's tree, ordered + culled
                                       // (4.1b), 2 = the same per lane, 0 = strict reference order
     rt_scene_info info;

@@ -328,3 +328,19 @@ def test_mesh_1m_distributed_ray_tracing_vs_oracle(mesh1m):
     bad = (np.abs(rad - orad) > 1e-4 * np.maximum(1.0, np.abs(orad))).any(-1)
     assert bad.sum() <= 0.005 * res[0] * res[1], (int(bad.sum()), float(np.abs(rad - orad).max()))
     assert st.rays_reflect > 1000 and st.passes >= 4
+
+
+def test_ray_sort_option_changes_no_byte(monkey_sd):
+    """RT_OPT_RAY_SORT hands the rays of the per-lane passes to lanes in (cell, octant, Morton) order: an order of work, not
+    of results -- the frame, the hit ids and the ray counts are the same bytes with it on or off"""
+    res = (200, 136)
+    kw = dict(spp=8, light_radius=0.3, glossy=0.1, seed=9)
+    g = host.Scene(monkey_sd)
+    cam = host.camera_for(monkey_sd, res)
+    base, ids, st = g.render(cam, host.default_params("hw4", **kw), want_ids=True)
+    abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_RAY_SORT, 1))
+    abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_LANE_DEPTH, 1))
+    srt, ids2, st2 = g.render(cam, host.default_params("hw4", **kw), want_ids=True)
+    assert np.array_equal(base, srt) and np.array_equal(ids, ids2)
+    assert (st.rays_reflect, st.rays_shadow) == (st2.rays_reflect, st2.rays_shadow) and st.rays_reflect > 10000
+    g.close()
