@@ -329,6 +329,6 @@ int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err) 
         for (int o = 0; o < 8; ++o) B.emit(root, 0, o, croot, flat->bvh_nodes[o]);
     }
     for (int k = 0; k < 3; ++k) flat->bvh_root_centre[k] = (float)croot[k];
-    if (flat->bvh_nodes[0].size() > (size_t)INT32_MAX / 2) { *err = "BVH exceeds 2^30 nodes"; return RT_E_LIMIT; }
+    if (flat->bvh_nodes[0].size() > (size_t)1 << 25) { *err = "BVH exceeds 2^25 nodes"; return RT_E_LIMIT; }   // 32-bit byte offsets on the device
     return RT_OK;
 }

@@ -551,7 +551,8 @@ __device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r,
         const float c = __builtin_fabsf(r.dx * nd.axis[0] + r.dy * nd.axis[1] + r.dz * nd.axis[2]) * b.rlen;
         const float cc = __builtin_fminf(c, 1.0f);
         const float lb = (cc * nd.cos_t - 2e-7f) - __builtin_amdgcn_sqrtf(1.0f - cc * cc) * nd.sin_t;   // cos(angle + cone) <= |dir . n| / |dir|
-        if (lb > 0.0f) lat = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
+        const float tight = __builtin_fminf(lat, nd.cone_k * __builtin_amdgcn_rcpf(lb) + 2e-5f);
+        lat = lb > 0.0f ? tight : lat;                                      // a select: no exec masking inside the box test
     }
     const float sl = __builtin_fmaf(lat, b.d0 + nd.rho, b.sl0);
     const rt_v2f s2 = {-sl, sl};
@@ -585,7 +586,9 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
     int i = 0;
     while (i < nn) {
         if (ANY) { if (rt_ballot(fail != RT_DEAD) == 0ull) break; }
-        const DevBvhNode nd = nodes[i];                   // wave-uniform address
+        // wave-uniform address; 32-bit byte offsets (the build keeps both tables below 2^32 bytes): one scalar shift or
+        // multiply per record instead of a 64-bit multiply-add
+        const DevBvhNode nd = *(const DevBvhNode*)((const char*)nodes + ((unsigned)i << 6));
         const int depth = nd.meta & 0xff;
         if (fail >= depth) fail = RT_ALIVE;
         bool hit = false;
@@ -600,7 +603,7 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
         if (leaf) {
             const int t0 = nd.skip, t1 = nd.skip + (nd.meta >> 16);
             for (int ti = t0; ti < t1; ++ti) {
-                const DevLeafTri* __restrict__ t = sc.bvh_tris + ti;                // wave-uniform
+                const DevLeafTri* __restrict__ t = (const DevLeafTri*)((const char*)sc.bvh_tris + (unsigned)ti * (unsigned)sizeof(DevLeafTri));
                 if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
                 const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
                 const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
