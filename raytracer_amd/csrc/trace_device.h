@@ -545,7 +545,7 @@ __device__ __forceinline__ BvhConsts bvh_consts(const DevSceneView& sc, const Ra
 // near parameter, exit = the smallest far one.  Otherwise the per-axis min / max sort them, as the reference's
 // HitTest does.  Same values either way: (-hi - sl) * (-1/d) is (hi + sl) * (1/d) exactly.
 template <bool UNI>
-__device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r, const BvhConsts& b, float limit) {
+__device__ __forceinline__ void bvh_box_interval(const DevBvhNode& nd, const Rayf& r, const BvhConsts& b, float& en, float& ex) {
     float lat = nd.slack;
     if (nd.meta & 0x200) {
         const float c = __builtin_fabsf(r.dx * nd.axis[0] + r.dy * nd.axis[1] + r.dz * nd.axis[2]) * b.rlen;
@@ -562,7 +562,6 @@ __device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r,
     x.x = __builtin_fmaf(x.x, b.rx, b.px); x.y = __builtin_fmaf(x.y, b.rx, b.px);
     y.x = __builtin_fmaf(y.x, b.ry, b.py); y.y = __builtin_fmaf(y.y, b.ry, b.py);
     z.x = __builtin_fmaf(z.x, b.rz, b.pz); z.y = __builtin_fmaf(z.y, b.rz, b.pz);
-    float en, ex;
     if (UNI) {
         en = __builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z.x);
         ex = __builtin_fminf(__builtin_fminf(x.y, y.y), z.y);
@@ -570,7 +569,27 @@ __device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r,
         en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
         ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
     }
+}
+template <bool UNI>
+__device__ __forceinline__ bool bvh_box_hit(const DevBvhNode& nd, const Rayf& r, const BvhConsts& b, float limit) {
+    float en, ex;
+    bvh_box_interval<UNI>(nd, r, b, en, ex);
     return !(ex < en || ex < 0.0f || en * b.dlen > limit);
+}
+// The same decision as a WAVE MASK (bit = lane), for the wave-synchronous walk: compare results stay in scalar registers,
+// where "no lane" is one scalar compare and "these lanes AND those" one scalar and -- no lane predicate is turned into
+// a register of 0 / 1 and compared again, no exec masking around the test.  Evaluated for every lane of the wave; the
+// caller masks.  Predicates are LLVM's: the U.. ones hold for unordered operands, as the negated tests above do.
+#define RT_FCMP_UGE 11
+#define RT_FCMP_ULE 13
+#define RT_ICMP_NE 33
+#define RT_ICMP_SGE 39
+template <bool UNI>
+__device__ __forceinline__ unsigned long long bvh_box_mask(const DevBvhNode& nd, const Rayf& r, const BvhConsts& b, float limit) {
+    float en, ex;
+    bvh_box_interval<UNI>(nd, r, b, en, ex);
+    // !(ex < en || ex < 0) = !(ex < max(en, 0)) (a NaN en leaves 0, as both tests on it would be false)
+    return __builtin_amdgcn_fcmpf(ex, __builtin_fmaxf(en, 0.0f), RT_FCMP_UGE) & __builtin_amdgcn_fcmpf(en * b.dlen, limit, RT_FCMP_ULE);
 }
 __device__ __forceinline__ bool bvh_fit(const RayAux& aux) { return aux.plain && aux.dlen > 0.999f && aux.dlen < 1.001f; }
 
@@ -584,22 +603,27 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
     const int nn = sc.nbvh;
     const BvhConsts bc = bvh_consts(sc, r, aux, sc.bvh_root_rho, oct);
     int i = 0;
+    // Lane sets are 64-bit wave masks in scalar registers (bvh_box_mask); inverse_ballot turns one back into a lane
+    // predicate where lanes diverge (the exact test of the few candidates).  All compares that build masks sit where the
+    // whole wave is active.
     while (i < nn) {
-        if (ANY) { if (rt_ballot(fail != RT_DEAD) == 0ull) break; }
+        if (ANY) { if (__builtin_amdgcn_sicmp(fail, RT_DEAD, RT_ICMP_NE) == 0ull) break; }
         // wave-uniform address; 32-bit byte offsets (the build keeps both tables below 2^32 bytes): one scalar shift or
         // multiply per record instead of a 64-bit multiply-add
-        const DevBvhNode nd = *(const DevBvhNode*)((const char*)nodes + ((unsigned)i << 6));
+        // Fetched as ONE 16-dword vector: field by field, the compiler sinks the cone's loads into the cone branch and splits
+        // the rest into five (seven scalar loads and a second wait per node)
+        typedef int rt_v16i __attribute__((ext_vector_type(16)));
+        const rt_v16i raw = *(const rt_v16i*)((const char*)nodes + ((unsigned)i << 6));
+        DevBvhNode nd;
+        __builtin_memcpy(&nd, &raw, sizeof nd);
         const int depth = nd.meta & 0xff;
-        if (fail >= depth) fail = RT_ALIVE;
-        bool hit = false;
-        if (COUNT) w->fetch += 1;
-        if (fail == RT_ALIVE) {
-            if (COUNT) w->box += 1;
-            hit = bvh_box_hit<UNI>(nd, r, bc, ANY ? far_limit : best.len);
-            if (!hit) fail = depth;
-        }
+        // the lanes that are at this node: alive, or waiting since a node at least this deep (RT_ALIVE is the largest int)
+        const unsigned long long in = __builtin_amdgcn_sicmp(fail, depth, RT_ICMP_SGE);
+        unsigned long long hm = in & bvh_box_mask<UNI>(nd, r, bc, ANY ? far_limit : best.len);
+        fail = __builtin_amdgcn_inverse_ballot_w64(hm) ? RT_ALIVE : (__builtin_amdgcn_inverse_ballot_w64(in) ? depth : fail);
+        if (COUNT) { w->fetch += 1; if (__builtin_amdgcn_inverse_ballot_w64(in)) w->box += 1; }
         const bool leaf = (nd.meta & 0x100) != 0;
-        if (rt_ballot(hit) == 0ull) { i = leaf ? i + 1 : nd.skip; continue; }
+        if (hm == 0ull) { i = leaf ? i + 1 : nd.skip; continue; }
         if (leaf) {
             const int t0 = nd.skip, t1 = nd.skip + (nd.meta >> 16);
             for (int ti = t0; ti < t1; ++ti) {
@@ -611,23 +635,25 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
                 const float pvy = r.dz * e2x - r.dx * e2z;
                 const float pvz = r.dx * e2y - r.dy * e2x;
                 const float det = e1x * pvx + e1y * pvy + e1z * pvz;
-                if (COUNT) { w->fetch += 1; if (hit) w->tri += 1; }
-                bool cand = hit && !(__builtin_fabsf(det) < eps_f);
+                if (COUNT) { w->fetch += 1; if (__builtin_amdgcn_inverse_ballot_w64(hm)) w->tri += 1; }
                 const float ri = __builtin_amdgcn_rcpf(det);
                 const float tx = r.ox - t->v0[0], ty = r.oy - t->v0[1], tz = r.oz - t->v0[2];
                 const float du = tx * pvx + ty * pvy + tz * pvz;
                 const float ua = du * ri;
-                cand = cand && !(ua < -1e-30f) && !(ua > 1.00001f);
-                if (rt_ballot(cand) == 0ull) continue;
+                // screen with the reciprocal: !(|det| < eps) && !(ua < -1e-30) && !(ua > 1.00001)
+                unsigned long long cm = hm & __builtin_amdgcn_fcmpf(__builtin_fabsf(det), eps_f, RT_FCMP_UGE) &
+                                        __builtin_amdgcn_fcmpf(ua, -1e-30f, RT_FCMP_UGE) & __builtin_amdgcn_fcmpf(ua, 1.00001f, RT_FCMP_ULE);
+                if (cm == 0ull) continue;
                 const float qx = ty * e1z - tz * e1y;
                 const float qy = tz * e1x - tx * e1z;
                 const float qz = tx * e1y - ty * e1x;
                 const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
                 const float dt = e2x * qx + e2y * qy + e2z * qz;
                 const float va = dv * ri, ta = dt * ri;
-                cand = cand && !(va < -1e-30f) && !(ua + va > 1.00002f) && !(ta < -1e-30f);
-                if (rt_ballot(cand) == 0ull) continue;
-                if (cand) {                                                          // hw4.cpp:211-230: the same values, tested together
+                cm &= __builtin_amdgcn_fcmpf(va, -1e-30f, RT_FCMP_UGE) & __builtin_amdgcn_fcmpf(ua + va, 1.00002f, RT_FCMP_ULE) &
+                      __builtin_amdgcn_fcmpf(ta, -1e-30f, RT_FCMP_UGE);
+                if (cm == 0ull) continue;
+                if (__builtin_amdgcn_inverse_ballot_w64(cm)) {                       // hw4.cpp:211-230: the same values, tested together
                     if (COUNT) w->exact += 1;
                     const float detInv = 1.0f / det;
                     const float u = du * detInv, v = dv * detInv, tt = dt * detInv;
@@ -636,7 +662,7 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
                         const float len = dist_to(r, px, py, pz);
                         if (ANY) {
                             if (len < far_limit && len >= sc.tol_f && reachable_rank(sc, t->rank, r) != 0x7fffffff) {
-                                occluded = true; fail = RT_DEAD; hit = false;
+                                occluded = true; fail = RT_DEAD;
                             }
                         } else if (len <= best.len && len >= sc.tol_f &&
                                    (!sc.culling || facing(sc, t->prim, false, r, px, py, pz))) {
@@ -647,6 +673,10 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
                             }
                         }
                     }
+                }
+                if (ANY) {                                                            // occluded lanes test no more triangles
+                    hm &= __builtin_amdgcn_sicmp(fail, RT_DEAD, RT_ICMP_NE);
+                    if (hm == 0ull) break;
                 }
             }
         }
