@@ -620,13 +620,14 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
         // the lanes that are at this node: alive, or waiting since a node at least this deep (RT_ALIVE is the largest int)
         const unsigned long long in = __builtin_amdgcn_sicmp(fail, depth, RT_ICMP_SGE);
         unsigned long long hm = in & bvh_box_mask<UNI>(nd, r, bc, ANY ? far_limit : best.len);
-        fail = __builtin_amdgcn_inverse_ballot_w64(hm) ? RT_ALIVE : (__builtin_amdgcn_inverse_ballot_w64(in) ? depth : fail);
+        // the lanes at this node hold fail >= depth, the others less: min() parks exactly the former at this depth
+        fail = __builtin_amdgcn_inverse_ballot_w64(hm) ? RT_ALIVE : (fail < depth ? fail : depth);
         if (COUNT) { w->fetch += 1; if (__builtin_amdgcn_inverse_ballot_w64(in)) w->box += 1; }
         const bool leaf = (nd.meta & 0x100) != 0;
-        if (hm == 0ull) { i = leaf ? i + 1 : nd.skip; continue; }
-        if (leaf) {
-            const int t0 = nd.skip, t1 = nd.skip + (nd.meta >> 16);
-            for (int ti = t0; ti < t1; ++ti) {
+        if (hm != 0ull && leaf) {
+            const int t1 = nd.skip + (nd.meta >> 16);                // a leaf holds at least one triangle
+            int ti = nd.skip;
+            do {
                 const DevLeafTri* __restrict__ t = (const DevLeafTri*)((const char*)sc.bvh_tris + (unsigned)ti * (unsigned)sizeof(DevLeafTri));
                 if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
                 const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
@@ -678,9 +679,9 @@ __device__ __forceinline__ void traverse_bvh_walk(const DevSceneView& sc, const 
                     hm &= __builtin_amdgcn_sicmp(fail, RT_DEAD, RT_ICMP_NE);
                     if (hm == 0ull) break;
                 }
-            }
+            } while (++ti < t1);
         }
-        i = i + 1;
+        i = (hm != 0ull || leaf) ? i + 1 : nd.skip;                  // (any-hit: hm may have emptied in the leaf, where it is i + 1 anyway)
     }
 }
 
