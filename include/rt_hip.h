@@ -368,6 +368,14 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, fl
 /* power_scale: ScalePhotonPower(power_scale, 0, n) after the balance as final.cpp:1126 does it, i.e.
  * heap slots 0..n-1 are scaled and slot n keeps its power (photon.cpp:826-833); 1.0f = leave.   */
 
+/* The same build with the photons RESIDENT ON THE DEVICE (the output of rt_photonmap_emit_dev, or of the all-gather
+ * that assembles a map): PhotonMap::balance / balance_segment / median_split (photon.cpp:133-254) replayed by kernels --
+ * every swap of the reference's quickselect, so photons that tie on a split axis land where the reference puts them --
+ * then ScalePhotonPower and the device image.  d_photons[0..n] (slot 0 unused) comes back in the reference's heap order,
+ * byte for byte what rt_photonmap_build leaves in its host array.  Synchronises the stream (one read-back per tree level).
+ * rt_photonmap_build itself takes this path through a temporary device copy when RT_PHOTON_BUILD=device.            */
+int rt_photonmap_build_dev(rt_scene* s, int which, rt_photon* d_photons, int64_t n, float power_scale, void* hip_stream);
+
 /* One build per node (no counterpart: the reference is one process).  With the map replicated on every GPU, one rank
  * balances and uploads (rt_photonmap_build) and the others copy its DEVICE IMAGE -- both heaps and the sub-heap boxes as
  * the kernels read them -- instead of repeating the host build: rt_photonmap_image_bytes gives its size, rt_photonmap_export_dev

@@ -95,7 +95,7 @@ SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info_get", "rt_scene_set_option", "rt_scene_knn_stats",
     "rt_host_flatten", "rt_host_flat_get", "rt_host_flat_free", "rt_host_photon_balance",
     "rt_trace_closest", "rt_trace_closest_dev", "rt_trace_any", "rt_trace_any_dev", "rt_trace_work_dev",
-    "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_emit", "rt_photonmap_emit_dev",
+    "rt_photonmap_upload", "rt_photonmap_build", "rt_photonmap_build_dev", "rt_photonmap_emit", "rt_photonmap_emit_dev",
     "rt_photonmap_image_bytes", "rt_photonmap_export_dev", "rt_photonmap_import_dev",
     "rt_photon_knn", "rt_photon_knn_dev", "rt_photon_knn_set", "rt_photon_irradiance", "rt_photon_irradiance_dev",
     "rt_photon_irradiance_noalloc_dev",
@@ -155,6 +155,7 @@ def load():
     if hasattr(L, "rt_photonmap_upload"):
         L.rt_photonmap_upload.argtypes = [vp, i32, vp, i64]
         L.rt_photonmap_build.argtypes = [vp, i32, vp, i64, C.c_float]
+        L.rt_photonmap_build_dev.argtypes = [vp, i32, vp, i64, C.c_float, vp]
         L.rt_photonmap_emit.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64)]
         L.rt_photonmap_emit_dev.argtypes = [vp, C.POINTER(rt_emit_params), i64, i64, vp, i64, C.POINTER(i64), vp]
         L.rt_photonmap_image_bytes.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]

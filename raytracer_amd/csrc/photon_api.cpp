@@ -3,6 +3,7 @@
 // (photon.cpp:133-254), kNN (photon.cpp:53-131) and irradiance (:342-443).
 #include "rt_scene.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -35,6 +36,12 @@ int check_map(rt_scene* s, int which, int k, const char* fn) {
     if (k < 1 || k > KNN_K_MAX) return rt_fail(RT_E_LIMIT, "%s: k=%d outside [1,%d]", fn, k, KNN_K_MAX);
     if (!s->pmap[which].d_photons) return rt_fail(RT_E_STATE, "%s: photon map %d not uploaded", fn, which);
     return RT_OK;
+}
+
+// RT_PHOTON_BUILD=host|device: where rt_photonmap_build balances and assembles (same bytes either way)
+bool photon_build_on_device() {
+    const char* e = getenv("RT_PHOTON_BUILD");
+    return e && strcmp(e, "device") == 0;
 }
 
 int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
@@ -132,11 +139,42 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, fl
     if (n >= ((int64_t)1 << 31) - 2) return rt_fail(RT_E_LIMIT, "rt_photonmap_build: more than 2^31 photons");
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    if (photon_build_on_device()) {                       // the same arrays, built by the kernels of photon_build_dev.hip
+        void* d = nullptr;
+        const size_t bytes = ((size_t)n + 1) * sizeof(rt_photon);
+        if (hipMalloc(&d, bytes) != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(%zu B of photons) failed", bytes);
+        int rc = RT_OK;
+        if (hipMemcpy(d, photons, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = rt_fail(RT_E_HIP, "copy photons");
+        if (!rc) rc = rt_photonmap_build_dev(s, which, (rt_photon*)d, n, power_scale, nullptr);
+        if (!rc && hipMemcpy(photons, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = rt_fail(RT_E_HIP, "copy photons back");
+        (void)hipFree(d);
+        return rc;
+    }
     try { rt_photon_balance_host(photons, n); } catch (const std::bad_alloc&) { return rt_fail(RT_E_NOMEM, "host allocation failed"); }
     if (power_scale != 1.0f)                              // ScalePhotonPower(scale, 0, n): slots 0..n-1, photon.cpp:826-833
         for (int64_t i = 0; i < n; ++i)
             for (int j = 0; j < 3; ++j) photons[i].power[j] = photons[i].power[j] * power_scale;
     return upload_heap(s, which, photons, n);
+}
+
+// The same build with the photons resident on the device (rt_photonmap_emit_dev's output): balance, scale and image by
+// the kernels of photon_build_dev.hip; d_photons comes back in the reference's heap order, as rt_photonmap_build leaves
+// its host array.
+int rt_photonmap_build_dev(rt_scene* s, int which, rt_photon* d_photons, int64_t n, float power_scale, void* stream) {
+    if (!s || which < 0 || which > 1 || n < 0 || !d_photons) return rt_fail(RT_E_INVALID, "rt_photonmap_build_dev: bad argument");
+    if (n >= ((int64_t)1 << 31) - 2) return rt_fail(RT_E_LIMIT, "rt_photonmap_build_dev: more than 2^31 photons");
+    DeviceGuard g(s->device);
+    if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
+    PhotonMapDev& m = s->pmap[which];
+    if (m.d_photons) { (void)hipFree(m.d_photons); m.d_photons = nullptr; m.n = 0; }
+    DevPhotonPos* img = nullptr; float box[6]; int status = 0;
+    const hipError_t e = rtk_photon_build_device(d_photons, n, power_scale, &img, box, (hipStream_t)stream, &status);
+    if (e == hipErrorOutOfMemory) return rt_fail(RT_E_NOMEM, "rt_photonmap_build_dev: device allocation failed");
+    if (e != hipSuccess) return rt_hipfail(e, "rt_photonmap_build_dev");
+    if (status) return rt_fail(RT_E_HIP, "rt_photonmap_build_dev: work queue overflow");
+    m.d_photons = img; m.n = n; m.half = n / 2 - 1;
+    memcpy(m.box, box, sizeof m.box);
+    return ensure_tables(s);
 }
 
 // ---- one build per node: the device image of a map, copied between ranks' GPUs ---------------------------------------

@@ -286,6 +286,8 @@ hipError_t rtk_pm_finalize(const int32_t* pixmap, int64_t nps, int ntap, int use
 
 // kernels_photon.hip
 size_t rtk_knn_lds_bytes(int k);
+hipError_t rtk_photon_build_device(rt_photon* d_photons, int64_t n, float power_scale, DevPhotonPos** d_image, float box6[6],
+                                   hipStream_t st, int* status);
 hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const float* d_pos3, const float* d_nrm3,
                           int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
                           float* d_r2, float* d_rgb, const float* d_tables, hipStream_t st);

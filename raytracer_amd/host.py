@@ -296,6 +296,11 @@ class Scene:
         abi.check(self.L.rt_photonmap_build(self.h, which, a.ctypes.data, a.shape[0] - 1, float(power_scale)))
         return a
 
+    def photonmap_build_dev(self, which, d_photons, n, power_scale=1.0, stream=None):
+        """the same build with the photons resident on the device: d_photons = address of rt_photon[n + 1] (slot 0 unused),
+        left in the reference's heap order (include/rt_hip.h: rt_photonmap_build_dev)."""
+        abi.check(self.L.rt_photonmap_build_dev(self.h, which, int(d_photons), int(n), float(power_scale), stream))
+
     def photonmap_emit(self, e, first, count, cap=None):
         """photons stored by emission indices [first, first+count), in emission order (0-based array)."""
         cap = int(count) * 2 + 64 if cap is None else int(cap)

@@ -263,3 +263,82 @@ def test_map_image_export_import_between_scenes():
     oi, od, of, _ = _oracle_knn(heap, qp[:500], 50, 0.3)
     assert np.array_equal(ia, ib) and np.array_equal(ib, oi) and db.tobytes() == od.tobytes() and np.array_equal(fb, of)
     a_scene.close(); b_scene.close()
+
+
+def _map_image(sc, which=0):
+    import torch
+    n, nb = C.c_int64(0), C.c_int64(0)
+    abi.check(sc.L.rt_photonmap_image_bytes(sc.h, which, C.byref(n), C.byref(nb)))
+    img = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+    box = (C.c_float * 6)()
+    abi.check(sc.L.rt_photonmap_export_dev(sc.h, which, img.data_ptr(), nb.value, box, None))
+    torch.cuda.synchronize()
+    return n.value, img.cpu().numpy(), np.array(list(box), np.float32)
+
+
+def _tie_map(n, seed, kind):
+    """maps that exercise median_split's handling of equal keys: 'wall' = photons on axis-aligned planes with the few distinct
+    coordinates a hit point's rounding leaves, 'grid' = every coordinate from a set of 7 values, 'same' = one point, 'sorted' /
+    'reversed' = distinct keys in order (the quickselect's worst pivots)."""
+    rng = np.random.default_rng(seed)
+    a = _random_map(n, seed)
+    p = a["position"][1:]
+    if kind == "wall":
+        third = n // 3
+        p[:third, 1] = np.float32(-0.5) + rng.integers(-1, 2, third).astype(np.float32) * np.float32(5.9604645e-08)
+        p[third:2 * third, 0] = np.float32(0.5)
+        p[2 * third:, 2] = rng.integers(-1, 2, n - 2 * third).astype(np.float32) * np.float32(1.4e-45)
+    elif kind == "grid":
+        p[:] = rng.integers(-3, 4, (n, 3)).astype(np.float32) * np.float32(0.125)
+    elif kind == "same":
+        p[:] = np.float32(0.25)
+    elif kind == "sorted":
+        p[:] = (np.arange(n, dtype=np.float32) / np.float32(n))[:, None]
+    elif kind == "reversed":
+        p[:] = (np.arange(n, 0, -1, dtype=np.float32) / np.float32(n))[:, None]
+    return a
+
+
+@pytest.mark.parametrize("n,kind", [(1, "random"), (2, "random"), (3, "grid"), (6, "random"), (7, "grid"), (100, "wall"), (1023, "wall"),
+                                    (1024, "grid"), (1025, "random"), (1025, "same"), (3000, "sorted"), (5000, "wall"), (9000, "reversed"),
+                                    (20_000, "grid"), (20_000, "same"), (50_000, "sorted"), (150_000, "random"), (150_000, "wall"),
+                                    (700_000, "wall"), (700_000, "grid")])
+def test_device_build_equals_host_build(n, kind):
+    """f2: rt_photonmap_build_dev (photon_build_dev.hip: the reference's balance replayed by kernels, both heaps, boxes, node
+    records) leaves the same bytes as rt_photonmap_build on the host -- the photons in heap order with their planes and
+    scaled powers, the device image, the box -- on maps with distinct keys and on maps where ties decide."""
+    import torch
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    a_scene, b_scene = host.Scene(sd), host.Scene(sd)
+    src = _tie_map(n, 1000 + n, kind) if kind != "random" else _random_map(n, 1000 + n)
+    scale = 0.37
+    h_heap = a_scene.photonmap_build(0, src.copy(), scale)
+    d = torch.from_numpy(src.copy().view(np.uint8)).cuda()
+    b_scene.photonmap_build_dev(0, d.data_ptr(), n, scale)
+    torch.cuda.synchronize()
+    d_heap = d.cpu().numpy().view(abi.photon_dtype)
+    assert h_heap[1:].tobytes() == d_heap[1:].tobytes()
+    assert h_heap["power"][0].tobytes() == d_heap["power"][0].tobytes()           # slot 0 is scaled too (photon.cpp:826-833)
+    na, ia, ba = _map_image(a_scene); nb_, ib, bb = _map_image(b_scene)
+    assert na == nb_ == n and ba.tobytes() == bb.tobytes()
+    assert ia.shape == ib.shape
+    if not np.array_equal(ia, ib):
+        bad = np.flatnonzero(ia != ib)
+        raise AssertionError(f"images differ at {bad.size} bytes, first at {bad[0]} of {ia.size} (record {bad[0] // 16})")
+    a_scene.close(); b_scene.close()
+
+
+def test_host_pointer_build_through_the_device(monkeypatch):
+    """RT_PHOTON_BUILD=device: rt_photonmap_build on a host array goes through the device builder and returns the same heap."""
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    a_scene, b_scene = host.Scene(sd), host.Scene(sd)
+    src = _tie_map(60_000, 5, "wall")
+    h = a_scene.photonmap_build(0, src.copy(), 1.0)
+    monkeypatch.setenv("RT_PHOTON_BUILD", "device")
+    dv = b_scene.photonmap_build(0, src.copy(), 1.0)
+    monkeypatch.delenv("RT_PHOTON_BUILD")
+    assert h[1:].tobytes() == dv[1:].tobytes()
+    qp = np.random.default_rng(6).uniform(-0.5, 0.5, (2000, 3)).astype(np.float32); qp[:800, 1] = -0.5
+    qn = np.random.default_rng(7).normal(size=qp.shape).astype(np.float32)
+    assert a_scene.photon_irradiance(0, qp, qn, 100, 0.3).tobytes() == b_scene.photon_irradiance(0, qp, qn, 100, 0.3).tobytes()
+    a_scene.close(); b_scene.close()
