@@ -14,22 +14,23 @@
 //  * inside a large segment, one partition pass pairs the k-th element from the left that is not < pivot with the k-th from
 //    the right that is not > pivot, for k = 1, 2, ... until the two scans meet.  While the two scans are in DISJOINT chunks
 //    the pairs of a chunk against a chunk are known without looking at anything else, and are swapped by 256 lanes at once
-//    (the order of the pairs is the serial one: both lists are consumed front to back).  Where the scans meet (<= 1026
-//    elements) lane 0 runs the reference's loop literally on an LDS copy.  A range of <= PB_SER elements is finished
-//    serially in LDS altogether.
+//    (the order of the pairs is the serial one: both lists are consumed front to back).  Where the scans meet (<= 3074
+//    elements) the zone is copied to LDS and finished by one more parallel step (pb_zone_pass: the same pairing over the
+//    whole zone, plus the rule for where the left scan ends).  A range of <= PB_ZONE elements stays in LDS for all its
+//    remaining passes.
 #include "rt_internal.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
 constexpr int PB_T = 256;                  // lanes per workgroup
 constexpr int PB_EBIG = 16;                // elements per lane in a big chunk
 constexpr int PB_CBIG = PB_T * PB_EBIG;    // 4096
-constexpr int PB_CSMALL = PB_T;            // 256
-constexpr int PB_SER = 1024;               // a range this short: all remaining passes serially in LDS
+constexpr int PB_EMID = 4;
+constexpr int PB_CMID = PB_T * PB_EMID;    // 1024
 constexpr int PB_SUB = 1024;               // a segment this short: its whole subtree in LDS
-constexpr int PB_WIN = 4 * PB_CSMALL + 8;  // LDS window of k_pb_big (>= PB_SER, >= the meeting zone)
 
 struct PbSeg { uint32_t index; int32_t start, end; float lo[3], hi[3]; };     // balance_segment's arguments
 
@@ -41,6 +42,7 @@ struct PbCtx {
     PbSeg* next; uint32_t* nnext; uint32_t cap_next;
     PbSeg* small; uint32_t* nsmall; uint32_t cap_small;
     uint32_t* overflow;
+    uint32_t* dbg;         // RT_PB_DEBUG: [0] most passes of a segment, [1] most serial steps, [2] most chunk rounds (per launch)
 };
 
 __device__ __forceinline__ float pb_comp(const float4& r, int axis) { return axis == 0 ? r.x : (axis == 1 ? r.y : r.z); }
@@ -146,13 +148,82 @@ __device__ void pb_finish_segment(const PbCtx& g, uint32_t index, int start, int
     }
 }
 
+// One whole partition pass of median_split over positions (i0, j0) of an LDS window (win[p - wbase] is org[p]), by all lanes.
+// State on entry, as the reference's loop would have it: i stands at i0 (everything up to i0 is behind the left scan), j
+// at j0, and position j0 is known to stop the left scan (the pivot itself, a swapped-in element, or an element > v).
+//   A = the positions in (i0, j0) that stop the left scan, ascending, then j0;  B = those that stop the right scan
+//   (`left` always does, photon.cpp:240), descending.
+// The reference swaps A[k] with B[k] for k = 0, 1, ... while A[k] < B[k]: between two swaps its scans only cross
+// positions no swap has touched yet -- the swapped ones are behind the scan that made them and ahead of the other.  At the
+// first k with A[k] >= B[k] (or B exhausted: the right scan runs into a swapped-in element or i0) the left scan stops at
+// A[k], or earlier at B[k-1], which now holds an element from the left: i = min(A[k], B[k-1]).  Returns i.
+constexpr int PB_ZONE = 4096;
+constexpr int PB_ZROWS = PB_ZONE / PB_T;
+struct PbZoneShared { int cnt[2][PB_ZROWS * (PB_T / 64)]; int pre[2][PB_ZROWS * (PB_T / 64)]; int tot[2]; int npairs; };
+__device__ int pb_zone_pass(float4* win, int wbase, int i0, int j0, int left, int axis, float v, int* listA, int* listB, PbZoneShared& zs) {
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int zlo = i0 + 1, zhi = j0 - 1;
+    const int rows = zhi >= zlo ? (zhi - zlo + PB_T) / PB_T : 0;
+    constexpr int NW = PB_T / 64;
+    unsigned fa = 0, fb = 0;
+    for (int r = 0; r < rows; ++r) {
+        const int p = zlo + r * PB_T + t;
+        bool a = false, b = false;
+        if (p <= zhi) {
+            const float key = pb_comp(win[p - wbase], axis);
+            a = !(key < v);
+            b = !(key > v) || p == left;
+        }
+        fa |= (a ? 1u : 0u) << r; fb |= (b ? 1u : 0u) << r;
+        const unsigned long long ba = __ballot(a), bb = __ballot(b);
+        if (lane == 0) { zs.cnt[0][r * NW + w] = __popcll(ba); zs.cnt[1][r * NW + w] = __popcll(bb); }
+    }
+    if (t == 0) zs.npairs = 0;
+    __syncthreads();
+    if (w < 2) {                                        // exclusive prefix of the (row, wave) counts: wave 0 for A, wave 1 for B
+        const int x = lane < rows * NW ? zs.cnt[w][lane] : 0;
+        int incl = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        zs.pre[w][lane] = incl - x;
+        if (lane == 63) zs.tot[w] = incl;
+    }
+    __syncthreads();
+    const int nA = zs.tot[0] + 1, nB = zs.tot[1];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int r = 0; r < rows; ++r) {
+        const bool a = (fa >> r) & 1u, b = (fb >> r) & 1u;
+        const unsigned long long ba = __ballot(a), bb = __ballot(b);
+        const int p = zlo + r * PB_T + t;
+        if (a) listA[zs.pre[0][r * NW + w] + __popcll(ba & below)] = p;
+        if (b) listB[nB - 1 - (zs.pre[1][r * NW + w] + __popcll(bb & below))] = p;
+    }
+    if (t == 0) listA[nA - 1] = j0;
+    __syncthreads();
+    const int nmin = min(nA, nB);
+    int mine = 0;
+    for (int k = t; k < nmin; k += PB_T) mine += listA[k] < listB[k] ? 1 : 0;     // a prefix: A ascends, B descends
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0 && mine) atomicAdd(&zs.npairs, mine);
+    __syncthreads();
+    const int np = zs.npairs;
+    for (int k = t; k < np; k += PB_T) {
+        const int pa = listA[k] - wbase, pb = listB[k] - wbase;
+        const float4 x = win[pa]; win[pa] = win[pb]; win[pb] = x;
+    }
+    const int ia = listA[np];                          // np < nA: the terminator j0 is never below an element of B
+    const int i = np >= 1 ? min(ia, listB[np - 1]) : ia;
+    __syncthreads();
+    return i;
+}
+
 // ---- one workgroup per segment of more than PB_SUB photons ---------------------------------------------------------------
 __global__ __launch_bounds__(PB_T) void k_pb_big(PbCtx g, const PbSeg* __restrict__ segs, uint32_t nsegs) {
-    __shared__ float4 win[PB_WIN];
-    __shared__ int listL[PB_CBIG], listR[PB_CBIG];
+    __shared__ float4 win[PB_ZONE + 8];
+    __shared__ int listL[PB_CBIG + 8], listR[PB_CBIG + 8];
     __shared__ int s_wsum[PB_T / 64];
     __shared__ float s_red[6][PB_T / 64];
-    __shared__ int s_i;
+    __shared__ PbZoneShared zs;
     const int t = threadIdx.x;
     if (blockIdx.x >= nsegs) return;
     const PbSeg sg = segs[blockIdx.x];
@@ -186,24 +257,35 @@ __global__ __launch_bounds__(PB_T) void k_pb_big(PbCtx g, const PbSeg* __restric
     const int axis = pb_axis(lo, hi);
 
     int left = start, right = end;                       // median_split; every lane holds the same values
+    uint32_t d_pass = 0, d_rounds = 0;
     while (right > left) {
         const int len = right - left + 1;
-        if (len <= PB_SER) {                             // the rest of the passes serially on an LDS copy
-            for (int p = t; p < len; p += PB_T) win[p] = g.org[left + p];
+        if (len <= PB_ZONE) {                            // the range fits the window: every remaining pass in LDS
+            const int wbase = left;
+            for (int p = t; p < len; p += PB_T) win[p] = g.org[wbase + p];
             __syncthreads();
-            if (t == 0) pb_split_window(win, left, left, right, median, axis);
-            __syncthreads();
-            for (int p = t; p < len; p += PB_T) g.org[left + p] = win[p];
+            int l = left, r = right;
+            while (r > l) {
+                ++d_pass;
+                const float v = pb_comp(win[r - wbase], axis);
+                const int i = pb_zone_pass(win, wbase, l - 1, r, l, axis, v, listL, listR, zs);
+                if (t == 0) { const float4 x = win[i - wbase]; win[i - wbase] = win[r - wbase]; win[r - wbase] = x; }
+                __syncthreads();
+                if (i >= median) r = i - 1;
+                if (i <= median) l = i + 1;
+            }
+            for (int p = t; p < len; p += PB_T) g.org[wbase + p] = win[p];
             __syncthreads();
             break;
         }
+        ++d_pass;
         const float v = pb_key(g.org, right, axis);
         int lo_p = left, hi_p = right - 1;               // next unscanned position of the left / right scan
         int nL = 0, offL = 0, nR = 0, offR = 0;
         bool big = true;
         for (;;) {
             int gap = hi_p - lo_p + 1;
-            if (big && gap < 2 * PB_CBIG) {              // near the meeting point: small chunks; what a big chunk left
+            if (big && gap < 2 * PB_CBIG) {              // near the meeting point: smaller chunks; what a big chunk left
                 big = false;                             // pending is handed back to be scanned again
                 if (nL > offL) lo_p = listL[offL];
                 if (nR > offR) hi_p = listR[offR];
@@ -211,16 +293,17 @@ __global__ __launch_bounds__(PB_T) void k_pb_big(PbCtx g, const PbSeg* __restric
                 gap = hi_p - lo_p + 1;
                 __syncthreads();
             }
-            const int ch = big ? PB_CBIG : PB_CSMALL;
+            const int ch = big ? PB_CBIG : PB_CMID;
             if (gap < 2 * ch) break;
             if (nL == offL) {
-                nL = big ? pb_scan_chunk<PB_EBIG, true>(g.org, lo_p, axis, v, listL, s_wsum) : pb_scan_chunk<1, true>(g.org, lo_p, axis, v, listL, s_wsum);
+                nL = big ? pb_scan_chunk<PB_EBIG, true>(g.org, lo_p, axis, v, listL, s_wsum) : pb_scan_chunk<PB_EMID, true>(g.org, lo_p, axis, v, listL, s_wsum);
                 offL = 0; lo_p += ch;
             }
             if (nR == offR) {
-                nR = big ? pb_scan_chunk<PB_EBIG, false>(g.org, hi_p, axis, v, listR, s_wsum) : pb_scan_chunk<1, false>(g.org, hi_p, axis, v, listR, s_wsum);
+                nR = big ? pb_scan_chunk<PB_EBIG, false>(g.org, hi_p, axis, v, listR, s_wsum) : pb_scan_chunk<PB_EMID, false>(g.org, hi_p, axis, v, listR, s_wsum);
                 offR = 0; hi_p -= ch;
             }
+            ++d_rounds;
             const int m = min(nL - offL, nR - offR);
             for (int q = t; q < m; q += PB_T) {
                 const int pa = listL[offL + q], pb = listR[offR + q];
@@ -230,44 +313,67 @@ __global__ __launch_bounds__(PB_T) void k_pb_big(PbCtx g, const PbSeg* __restric
             offL += m; offR += m;
             __syncthreads();
         }
-        // the meeting zone: the reference's loop from where the two scans stand.  i: the next position it tests is the
-        // first pending left stop (everything before it was scanned and is < v), else the first unscanned one; j alike.
+        // the meeting zone, in LDS: the reference's loop from where the two scans stand.  i: the next position it tests is
+        // the first pending left stop (everything before it was scanned and is < v), else the first unscanned one; j alike
+        // (position j0 holds an element that stops the left scan: swapped in, scanned as > v, or the pivot).
         const int i0 = (nL > offL ? listL[offL] : lo_p) - 1;
         const int j0 = (nR > offR ? listR[offR] : hi_p) + 1;
-        const int wlo = max(i0, left), whi = min(j0, right);          // i stops at j0 at the latest, j at i0 (or left)
-        const int wn = whi - wlo + 1;                                  // <= 4 * PB_CSMALL + 2
+        const int wlo = max(i0, left), whi = j0;                       // <= gap + one mid chunk + 2 positions
+        const int wn = whi - wlo + 1;
         __syncthreads();
         for (int p = t; p < wn; p += PB_T) win[p] = g.org[wlo + p];
         __syncthreads();
-        if (t == 0) {
-            int i = i0, j = j0;
-            for (;;) {
-                while (pb_comp(win[++i - wlo], axis) < v) {}
-                while (pb_comp(win[--j - wlo], axis) > v && j > left) {}
-                if (i >= j) break;
-                const float4 x = win[i - wlo]; win[i - wlo] = win[j - wlo]; win[j - wlo] = x;
-            }
-            if (right <= whi) { const float4 x = win[i - wlo]; win[i - wlo] = win[right - wlo]; win[right - wlo] = x; }
-            s_i = i;
-        }
+        const int i = pb_zone_pass(win, wlo, i0, j0, left, axis, v, listL, listR, zs);
+        if (right == whi && t == 0) { const float4 x = win[i - wlo]; win[i - wlo] = win[right - wlo]; win[right - wlo] = x; }
         __syncthreads();
         for (int p = t; p < wn; p += PB_T) g.org[wlo + p] = win[p];
         __syncthreads();
-        const int i = s_i;
         if (right > whi && t == 0) { const float4 a = g.org[i], b = g.org[right]; g.org[i] = b; g.org[right] = a; }
         __syncthreads();
         if (i >= median) right = i - 1;
         if (i <= median) left = i + 1;
     }
-    if (t == 0) pb_finish_segment(g, sg.index, start, end, median, axis, lo, hi);
+    if (t == 0) {
+        pb_finish_segment(g, sg.index, start, end, median, axis, lo, hi);
+        if (g.dbg) { atomicMax(g.dbg, d_pass); atomicMax(g.dbg + 2, d_rounds); }
+    }
 }
 
 // ---- one workgroup per segment of <= PB_SUB photons: the whole subtree in LDS, one lane per sub-segment -----------------
 struct PbSub { uint32_t index; uint16_t start, end; float lo[3], hi[3]; };      // start / end relative to the segment
+constexpr int PB_LANE = 128;               // a sub-segment this short: one lane
+// the node of a sub-segment after its split, and its halves (as pb_finish_segment, inside the LDS window)
+__device__ void pb_small_children(const PbCtx& g, const float4* w, const PbSub& s, int start, int end, int median, int axis,
+                                  const float* lo, const float* hi, PbSub* out, int* nout) {
+    const float4 node = w[median];
+    const int nidx = __float_as_int(node.w);
+    g.bal[s.index] = nidx;
+    g.plane[nidx] = (int8_t)axis;
+    const float cut = pb_comp(node, axis);
+    if (median > start) {
+        if (start < median - 1) {
+            PbSub c; c.index = 2u * s.index; c.start = (uint16_t)start; c.end = (uint16_t)(median - 1);
+            for (int k = 0; k < 3; ++k) { c.lo[k] = lo[k]; c.hi[k] = hi[k]; }
+            c.hi[axis] = cut;
+            out[atomicAdd(nout, 1)] = c;
+        } else g.bal[2u * s.index] = __float_as_int(w[start].w);
+    }
+    if (median < end) {
+        if (median + 1 < end) {
+            PbSub c; c.index = 2u * s.index + 1u; c.start = (uint16_t)(median + 1); c.end = (uint16_t)end;
+            for (int k = 0; k < 3; ++k) { c.lo[k] = lo[k]; c.hi[k] = hi[k]; }
+            c.lo[axis] = cut;
+            out[atomicAdd(nout, 1)] = c;
+        } else g.bal[2u * s.index + 1u] = __float_as_int(w[end].w);
+    }
+}
 __global__ __launch_bounds__(PB_T) void k_pb_small(PbCtx g, const PbSeg* __restrict__ segs, uint32_t nsegs) {
     __shared__ float4 w[PB_SUB];
     __shared__ PbSub lists[2][PB_SUB / 2 + 1];
     __shared__ int s_n[2];
+    __shared__ int listA[PB_SUB + 8], listB[PB_SUB + 8];
+    __shared__ float s_red[6][PB_T / 64];
+    __shared__ PbZoneShared zs;
     const int t = threadIdx.x;
     if (blockIdx.x >= nsegs) return;
     const PbSeg sg = segs[blockIdx.x];
@@ -283,9 +389,55 @@ __global__ __launch_bounds__(PB_T) void k_pb_small(PbCtx g, const PbSeg* __restr
     for (;;) {
         const int ns = s_n[cur];
         if (ns == 0) break;
+        // sub-segments of more than PB_LANE photons (the top levels of the subtree, a handful): one after the other, every
+        // pass by the whole workgroup (pb_zone_pass); the rest: one lane each, the reference's loop as it stands
+        for (int q = 0; q < ns; ++q) {
+            const PbSub s = lists[cur][q];
+            const int start = s.start, end = s.end;
+            if (end - start + 1 <= PB_LANE) continue;
+            const int median = pb_median(start, end);
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) { lo[k] = s.lo[k]; hi[k] = s.hi[k]; }
+            if (g.tight) {
+                float l[3] = {1e30f, 1e30f, 1e30f}, h[3] = {-1e30f, -1e30f, -1e30f};
+                for (int p = start + t; p <= end; p += PB_T) {
+                    const float4 r = w[p];
+                    const float c[3] = {r.x, r.y, r.z};
+                    for (int k = 0; k < 3; ++k) { if (c[k] < l[k]) l[k] = c[k]; if (c[k] > h[k]) h[k] = c[k]; }
+                }
+                for (int k = 0; k < 3; ++k) {
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        const float ol = __shfl_xor(l[k], d, 64), oh = __shfl_xor(h[k], d, 64);
+                        if (ol < l[k]) l[k] = ol;
+                        if (oh > h[k]) h[k] = oh;
+                    }
+                    if ((t & 63) == 0) { s_red[k][t >> 6] = l[k]; s_red[3 + k][t >> 6] = h[k]; }
+                }
+                __syncthreads();
+                for (int k = 0; k < 3; ++k) {
+                    float a = s_red[k][0], b = s_red[3 + k][0];
+                    for (int z = 1; z < PB_T / 64; ++z) { if (s_red[k][z] < a) a = s_red[k][z]; if (s_red[3 + k][z] > b) b = s_red[3 + k][z]; }
+                    lo[k] = a; hi[k] = b;
+                }
+                __syncthreads();
+            }
+            const int axis = pb_axis(lo, hi);
+            int l = start, r = end;
+            while (r > l) {
+                const float v = pb_comp(w[r], axis);
+                const int i = pb_zone_pass(w, 0, l - 1, r, l, axis, v, listA, listB, zs);
+                if (t == 0) { const float4 x = w[i]; w[i] = w[r]; w[r] = x; }
+                __syncthreads();
+                if (i >= median) r = i - 1;
+                if (i <= median) l = i + 1;
+            }
+            if (t == 0) pb_small_children(g, w, s, start, end, median, axis, lo, hi, lists[cur ^ 1], &s_n[cur ^ 1]);
+        }
+        __syncthreads();
         for (int q = t; q < ns; q += PB_T) {
             const PbSub s = lists[cur][q];
             const int start = s.start, end = s.end;
+            if (end - start + 1 > PB_LANE) continue;
             const int median = pb_median(start, end);
             float lo[3], hi[3];
             for (int k = 0; k < 3; ++k) { lo[k] = s.lo[k]; hi[k] = s.hi[k]; }
@@ -299,27 +451,7 @@ __global__ __launch_bounds__(PB_T) void k_pb_small(PbCtx g, const PbSeg* __restr
             }
             const int axis = pb_axis(lo, hi);
             pb_split_window(w, 0, start, end, median, axis);
-            const float4 node = w[median];
-            const int nidx = __float_as_int(node.w);
-            g.bal[s.index] = nidx;
-            g.plane[nidx] = (int8_t)axis;
-            const float cut = pb_comp(node, axis);
-            if (median > start) {
-                if (start < median - 1) {
-                    PbSub c; c.index = 2u * s.index; c.start = (uint16_t)start; c.end = (uint16_t)(median - 1);
-                    for (int k = 0; k < 3; ++k) { c.lo[k] = lo[k]; c.hi[k] = hi[k]; }
-                    c.hi[axis] = cut;
-                    lists[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = c;
-                } else g.bal[2u * s.index] = __float_as_int(w[start].w);
-            }
-            if (median < end) {
-                if (median + 1 < end) {
-                    PbSub c; c.index = 2u * s.index + 1u; c.start = (uint16_t)(median + 1); c.end = (uint16_t)end;
-                    for (int k = 0; k < 3; ++k) { c.lo[k] = lo[k]; c.hi[k] = hi[k]; }
-                    c.lo[axis] = cut;
-                    lists[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = c;
-                } else g.bal[2u * s.index + 1u] = __float_as_int(w[end].w);
-            }
+            pb_small_children(g, w, s, start, end, median, axis, lo, hi, lists[cur ^ 1], &s_n[cur ^ 1]);
         }
         __syncthreads();
         if (t == 0) s_n[cur] = 0;
@@ -485,14 +617,16 @@ hipError_t pb_balance(float4* d_org, int64_t n, int tight, const float lo0[3], c
     const uint32_t cap_big = (uint32_t)(n / PB_SUB + 2), cap_small = (uint32_t)(4 * (n / PB_SUB + 2) + 2);
     DevBuf qa, qb, qs, cnt;
     PBCHK(qa.alloc((size_t)cap_big * sizeof(PbSeg))); PBCHK(qb.alloc((size_t)cap_big * sizeof(PbSeg)));
-    PBCHK(qs.alloc((size_t)cap_small * sizeof(PbSeg))); PBCHK(cnt.alloc(16));
-    PBCHK(hipMemsetAsync(cnt.p, 0, 16, st));
+    PBCHK(qs.alloc((size_t)cap_small * sizeof(PbSeg))); PBCHK(cnt.alloc(32));
+    PBCHK(hipMemsetAsync(cnt.p, 0, 32, st));
+    const bool debug = getenv("RT_PB_DEBUG") != nullptr;
     uint32_t* d_cnt = cnt.as<uint32_t>();               // [0] next big, [1] small, [2] overflow
     PbSeg root; root.index = 1; root.start = 1; root.end = (int32_t)n;
     for (int k = 0; k < 3; ++k) { root.lo[k] = lo0[k]; root.hi[k] = hi0[k]; }
     PbCtx g;
     g.org = d_org; g.bal = d_bal; g.plane = d_plane; g.tight = tight;
     g.nnext = d_cnt; g.cap_next = cap_big; g.small = qs.as<PbSeg>(); g.nsmall = d_cnt + 1; g.cap_small = cap_small; g.overflow = d_cnt + 2;
+    g.dbg = debug ? d_cnt + 4 : nullptr;
     uint32_t nbig = 0, h[3] = {0, 0, 0};
     PbSeg* cur = qa.as<PbSeg>(); PbSeg* nxt = qb.as<PbSeg>();
     if (n > PB_SUB) { PBCHK(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st)); nbig = 1; }
@@ -505,6 +639,12 @@ hipError_t pb_balance(float4* d_org, int64_t n, int tight, const float lo0[3], c
         PBCHK(hipMemcpyAsync(h, d_cnt, 12, hipMemcpyDeviceToHost, st));
         PBCHK(hipStreamSynchronize(st));
         if (h[2]) { *overflow_out = 1; return hipSuccess; }
+        if (debug) {
+            uint32_t d[3];
+            PBCHK(hipMemcpy(d, d_cnt + 4, 12, hipMemcpyDeviceToHost));
+            PBCHK(hipMemset(d_cnt + 4, 0, 12));
+            fprintf(stderr, "[pb] tight=%d segments=%u: most passes %u, serial steps %u, chunk rounds %u\n", tight, nbig, d[0], d[1], d[2]);
+        }
         nbig = h[0];
         PBCHK(hipMemsetAsync(d_cnt, 0, 4, st));
         PbSeg* x = cur; cur = nxt; nxt = x;
