@@ -32,7 +32,11 @@ constexpr int PB_EMID = 4;
 constexpr int PB_CMID = PB_T * PB_EMID;    // 1024
 constexpr int PB_SUB = 1024;               // a segment this short: its whole subtree in LDS
 
-struct PbSeg { uint32_t index; int32_t start, end; float lo[3], hi[3]; };     // balance_segment's arguments
+struct PbSeg {                 // balance_segment's arguments, and how far the wide passes (below) have taken its median_split
+    uint32_t index; int32_t start, end; float lo[3], hi[3];
+    int32_t left, right;       // median_split's current range: start, end when nothing has run yet
+    int32_t have_box;          // tight: lo / hi already hold the segment's own bounding box
+};
 
 struct PbCtx {
     float4* org;           // porg with the position beside the index: {x, y, z, bits of idx}, 1-based
@@ -130,7 +134,7 @@ __device__ void pb_finish_segment(const PbCtx& g, uint32_t index, int start, int
     const float cut = pb_comp(node, axis);
     if (median > start) {
         if (start < median - 1) {
-            PbSeg s; s.index = 2u * index; s.start = start; s.end = median - 1;
+            PbSeg s; s.index = 2u * index; s.start = s.left = start; s.end = s.right = median - 1; s.have_box = 0;
             for (int k = 0; k < 3; ++k) { s.lo[k] = lo[k]; s.hi[k] = hi[k]; }
             s.hi[axis] = cut;
             if (s.end - s.start + 1 > PB_SUB) pb_push(g.next, g.nnext, g.cap_next, g.overflow, s);
@@ -139,7 +143,7 @@ __device__ void pb_finish_segment(const PbCtx& g, uint32_t index, int start, int
     }
     if (median < end) {
         if (median + 1 < end) {
-            PbSeg s; s.index = 2u * index + 1u; s.start = median + 1; s.end = end;
+            PbSeg s; s.index = 2u * index + 1u; s.start = s.left = median + 1; s.end = s.right = end; s.have_box = 0;
             for (int k = 0; k < 3; ++k) { s.lo[k] = lo[k]; s.hi[k] = hi[k]; }
             s.lo[axis] = cut;
             if (s.end - s.start + 1 > PB_SUB) pb_push(g.next, g.nnext, g.cap_next, g.overflow, s);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(PB_T) void k_pb_big(PbCtx g, const PbSeg* __restric
     const int median = pb_median(start, end);
     float lo[3], hi[3];
     for (int k = 0; k < 3; ++k) { lo[k] = sg.lo[k]; hi[k] = sg.hi[k]; }
-    if (g.tight) {                       // the segment's own bounding box (photon_build.cpp: Balancer::segment, tight)
+    if (g.tight && !sg.have_box) {       // the segment's own bounding box (photon_build.cpp: Balancer::segment, tight)
         float l[3] = {1e30f, 1e30f, 1e30f}, h[3] = {-1e30f, -1e30f, -1e30f};
         for (int p = start + t; p <= end; p += PB_T) {
             const float4 r = g.org[p];
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(PB_T) void k_pb_big(PbCtx g, const PbSeg* __restric
     }
     const int axis = pb_axis(lo, hi);
 
-    int left = start, right = end;                       // median_split; every lane holds the same values
+    int left = sg.left, right = sg.right;                // median_split (from where the wide passes left it); uniform
     uint32_t d_pass = 0, d_rounds = 0;
     while (right > left) {
         const int len = right - left + 1;
@@ -460,6 +464,260 @@ __global__ __launch_bounds__(PB_T) void k_pb_small(PbCtx g, const PbSeg* __restr
     }
 }
 
+// ---- wide passes: the partition passes of LARGE ranges, every segment of the level at once, the whole GPU on each ---------
+// The pairing of pb_zone_pass holds for a zone of any size, so a pass over a range of millions of photons is: flag the
+// positions that stop either scan (tiles of PBW_TILE positions), scan the tile counts, scatter the two lists, find how
+// many pairs cross (A ascends, B descends: a binary search), swap them, move the pivot.  Seven small launches per pass
+// for all the level's segments together, instead of one workgroup streaming a range alone; a segment leaves the wide
+// passes when its range is down to PBW_KEEP photons (k_pb_big continues from PbSeg::left / right).
+constexpr int PBW_E = 8;
+constexpr int PBW_TILE = PB_T * PBW_E;     // 2048
+constexpr int PBW_MIN = 131072;            // segments larger than this start with wide passes
+constexpr int PBW_KEEP = 32768;            // ... and stay while the range is larger than this
+struct PbWide { int active, left, right, median, axis, nA, nB, np, i, tile0, ntiles; float v; };
+
+__global__ void k_pbw_init(const PbSeg* __restrict__ segs, uint32_t nsegs, int tight, PbWide* wd, uint32_t* d_nwide) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsegs) return;
+    const PbSeg sg = segs[s];
+    PbWide w;
+    w.active = sg.end - sg.start + 1 > PBW_MIN ? 1 : 0;
+    w.left = sg.start; w.right = sg.end; w.median = pb_median(sg.start, sg.end);
+    w.axis = tight ? 0 : pb_axis(sg.lo, sg.hi);
+    w.nA = w.nB = w.np = w.i = 0; w.v = 0.f;
+    w.tile0 = 0; w.ntiles = w.active ? (sg.end - sg.start + 1 + PBW_TILE - 1) / PBW_TILE : 0;      // for the box (tight)
+    wd[s] = w;
+    if (w.active) atomicAdd(d_nwide, 1u);
+}
+// exclusive scan of ntiles over the segments -> tile0, total -> *d_total (one workgroup)
+__global__ __launch_bounds__(PB_T) void k_pbw_tiles(PbWide* wd, uint32_t nsegs, uint32_t* d_total) {
+    __shared__ int s_w[PB_T / 64];
+    __shared__ int s_carry;
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nsegs; base += PB_T) {
+        const uint32_t s = base + t;
+        const int x = s < nsegs ? wd[s].ntiles : 0;
+        int incl = x;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if ((t & 63) >= d) incl += o; }
+        if ((t & 63) == 63) s_w[t >> 6] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int k = 0; k < PB_T / 64; ++k) { if (k < (t >> 6)) woff += s_w[k]; total += s_w[k]; }
+        const int carry = s_carry;
+        if (s < nsegs) wd[s].tile0 = carry + woff + incl - x;
+        __syncthreads();
+        if (t == 0) s_carry = carry + total;
+        __syncthreads();
+    }
+    if (t == 0) *d_total = (uint32_t)s_carry;
+}
+// the segment a tile belongs to: the last one whose tile0 <= tile (segments without tiles share the tile0 of their successor)
+__device__ __forceinline__ uint32_t pbw_find(const PbWide* wd, uint32_t nsegs, int tile) {
+    uint32_t lo = 0, hi = nsegs - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (wd[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// tight: the box of a wide segment, tile partials then one workgroup per segment
+__global__ __launch_bounds__(PB_T) void k_pbw_box_tiles(const float4* __restrict__ org, const PbSeg* __restrict__ segs, const PbWide* __restrict__ wd,
+                                                        uint32_t nsegs, float* partial) {
+    __shared__ float s_red[6][PB_T / 64];
+    const int t = threadIdx.x;
+    const uint32_t s = pbw_find(wd, nsegs, (int)blockIdx.x);
+    const int tile = (int)blockIdx.x - wd[s].tile0;
+    const int first = segs[s].start + tile * PBW_TILE, last = min(first + PBW_TILE - 1, segs[s].end);
+    float l[3] = {1e30f, 1e30f, 1e30f}, h[3] = {-1e30f, -1e30f, -1e30f};
+    for (int p = first + t; p <= last; p += PB_T) {
+        const float4 r = org[p];
+        const float c[3] = {r.x, r.y, r.z};
+        for (int k = 0; k < 3; ++k) { if (c[k] < l[k]) l[k] = c[k]; if (c[k] > h[k]) h[k] = c[k]; }
+    }
+    for (int k = 0; k < 3; ++k) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ol = __shfl_xor(l[k], d, 64), oh = __shfl_xor(h[k], d, 64);
+            if (ol < l[k]) l[k] = ol;
+            if (oh > h[k]) h[k] = oh;
+        }
+        if ((t & 63) == 0) { s_red[k][t >> 6] = l[k]; s_red[3 + k][t >> 6] = h[k]; }
+    }
+    __syncthreads();
+    if (t < 3) {
+        float a = s_red[t][0], b = s_red[3 + t][0];
+        for (int q = 1; q < PB_T / 64; ++q) { if (s_red[t][q] < a) a = s_red[t][q]; if (s_red[3 + t][q] > b) b = s_red[3 + t][q]; }
+        partial[(size_t)blockIdx.x * 6 + t] = a; partial[(size_t)blockIdx.x * 6 + 3 + t] = b;
+    }
+}
+__global__ __launch_bounds__(PB_T) void k_pbw_box_reduce(PbSeg* segs, PbWide* wd, uint32_t nsegs, const float* __restrict__ partial) {
+    __shared__ float s_red[6][PB_T / 64];
+    const uint32_t s = blockIdx.x;
+    const int t = threadIdx.x;
+    if (s >= nsegs || !wd[s].active) return;
+    const int t0 = wd[s].tile0, nt = wd[s].ntiles;
+    float l[3] = {1e30f, 1e30f, 1e30f}, h[3] = {-1e30f, -1e30f, -1e30f};
+    for (int q = t; q < nt; q += PB_T)
+        for (int k = 0; k < 3; ++k) {
+            const float a = partial[(size_t)(t0 + q) * 6 + k], b = partial[(size_t)(t0 + q) * 6 + 3 + k];
+            if (a < l[k]) l[k] = a;
+            if (b > h[k]) h[k] = b;
+        }
+    for (int k = 0; k < 3; ++k) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float ol = __shfl_xor(l[k], d, 64), oh = __shfl_xor(h[k], d, 64);
+            if (ol < l[k]) l[k] = ol;
+            if (oh > h[k]) h[k] = oh;
+        }
+        if ((t & 63) == 0) { s_red[k][t >> 6] = l[k]; s_red[3 + k][t >> 6] = h[k]; }
+    }
+    __syncthreads();
+    if (t == 0) {
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            float a = s_red[k][0], b = s_red[3 + k][0];
+            for (int q = 1; q < PB_T / 64; ++q) { if (s_red[k][q] < a) a = s_red[k][q]; if (s_red[3 + k][q] > b) b = s_red[3 + k][q]; }
+            lo[k] = a; hi[k] = b; segs[s].lo[k] = a; segs[s].hi[k] = b;
+        }
+        segs[s].have_box = 1;
+        wd[s].axis = pb_axis(lo, hi);
+    }
+}
+// per pass: which segments still take a wide pass, their pivot and tiles (ntiles; k_pbw_tiles scans them)
+__global__ void k_pbw_plan(const float4* __restrict__ org, PbWide* wd, uint32_t nsegs) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsegs) return;
+    PbWide w = wd[s];
+    if (w.active && !(w.right > w.left && w.right - w.left + 1 > PBW_KEEP)) w.active = 0;
+    w.ntiles = 0;
+    if (w.active) {
+        w.v = pb_key(org, w.right, w.axis);
+        w.ntiles = (w.right - w.left + PBW_TILE - 1) / PBW_TILE;                 // positions left .. right - 1
+    }
+    wd[s] = w;
+}
+// flags of one tile: bit e of fa / fb = position first + t * PBW_E + e stops the left / right scan
+__device__ __forceinline__ void pbw_flags(const float4* org, const PbWide& w, int first, int t, unsigned& fa, unsigned& fb) {
+    fa = fb = 0;
+#pragma unroll
+    for (int e = 0; e < PBW_E; ++e) {
+        const int p = first + t * PBW_E + e;
+        if (p < w.right) {
+            const float key = pb_key(org, p, w.axis);
+            fa |= (!(key < w.v) ? 1u : 0u) << e;
+            fb |= ((!(key > w.v) || p == w.left) ? 1u : 0u) << e;
+        }
+    }
+}
+// block-wide exclusive scan of two per-lane counts
+__device__ __forceinline__ void pbw_scan2(int ca, int cb, int& offa, int& offb, int& tota, int& totb, int (*s_w)[PB_T / 64]) {
+    const int t = threadIdx.x;
+    int ia = ca, ib = cb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+        if ((t & 63) >= d) { ia += oa; ib += ob; }
+    }
+    if ((t & 63) == 63) { s_w[0][t >> 6] = ia; s_w[1][t >> 6] = ib; }
+    __syncthreads();
+    int wa = 0, wb = 0; tota = totb = 0;
+#pragma unroll
+    for (int k = 0; k < PB_T / 64; ++k) { if (k < (t >> 6)) { wa += s_w[0][k]; wb += s_w[1][k]; } tota += s_w[0][k]; totb += s_w[1][k]; }
+    offa = wa + ia - ca; offb = wb + ib - cb;
+    __syncthreads();
+}
+__global__ __launch_bounds__(PB_T) void k_pbw_count(const float4* __restrict__ org, const PbWide* __restrict__ wd, uint32_t nsegs, int2* tcnt) {
+    __shared__ int s_w[2][PB_T / 64];
+    const uint32_t s = pbw_find(wd, nsegs, (int)blockIdx.x);
+    const PbWide w = wd[s];
+    const int first = w.left + ((int)blockIdx.x - w.tile0) * PBW_TILE;
+    unsigned fa, fb;
+    pbw_flags(org, w, first, threadIdx.x, fa, fb);
+    int oa, ob, ta, tb;
+    pbw_scan2(__popc(fa), __popc(fb), oa, ob, ta, tb, s_w);
+    if (threadIdx.x == 0) tcnt[blockIdx.x] = make_int2(ta, tb);
+}
+__global__ __launch_bounds__(PB_T) void k_pbw_scan(PbWide* wd, uint32_t nsegs, const int2* __restrict__ tcnt, int2* toff) {
+    __shared__ int s_w[2][PB_T / 64];
+    __shared__ int s_carry[2];
+    const uint32_t s = blockIdx.x;
+    const int t = threadIdx.x;
+    if (s >= nsegs || !wd[s].active) return;
+    const int t0 = wd[s].tile0, nt = wd[s].ntiles;
+    if (t == 0) { s_carry[0] = 0; s_carry[1] = 0; }
+    __syncthreads();
+    for (int base = 0; base < nt; base += PB_T) {
+        const int q = base + t;
+        const int2 c = q < nt ? tcnt[t0 + q] : make_int2(0, 0);
+        int oa, ob, ta, tb;
+        pbw_scan2(c.x, c.y, oa, ob, ta, tb, s_w);
+        const int ca = s_carry[0], cb = s_carry[1];
+        if (q < nt) toff[t0 + q] = make_int2(ca + oa, cb + ob);
+        __syncthreads();
+        if (t == 0) { s_carry[0] = ca + ta; s_carry[1] = cb + tb; }
+        __syncthreads();
+    }
+    if (t == 0) { wd[s].nA = s_carry[0] + 1; wd[s].nB = s_carry[1]; }
+}
+__global__ __launch_bounds__(PB_T) void k_pbw_scatter(const float4* __restrict__ org, const PbWide* __restrict__ wd, uint32_t nsegs,
+                                                      const int2* __restrict__ toff, int* gA, int* gB) {
+    __shared__ int s_w[2][PB_T / 64];
+    const uint32_t s = pbw_find(wd, nsegs, (int)blockIdx.x);
+    const PbWide w = wd[s];
+    const int tile = (int)blockIdx.x - w.tile0;
+    const int first = w.left + tile * PBW_TILE;
+    unsigned fa, fb;
+    pbw_flags(org, w, first, threadIdx.x, fa, fb);
+    int oa, ob, ta, tb;
+    pbw_scan2(__popc(fa), __popc(fb), oa, ob, ta, tb, s_w);
+    const int2 off = toff[blockIdx.x];
+    int ka = off.x + oa, kb = off.y + ob;
+#pragma unroll
+    for (int e = 0; e < PBW_E; ++e) {
+        const int p = first + threadIdx.x * PBW_E + e;
+        if ((fa >> e) & 1u) gA[w.left + ka++] = p;
+        if ((fb >> e) & 1u) gB[w.left + (w.nB - 1 - kb++)] = p;
+    }
+    if (tile == 0 && threadIdx.x == 0) gA[w.left + w.nA - 1] = w.right;            // the terminator: the pivot stops the left scan
+}
+__global__ void k_pbw_pairs(PbWide* wd, uint32_t nsegs, const int* __restrict__ gA, const int* __restrict__ gB) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsegs || !wd[s].active) return;
+    const PbWide w = wd[s];
+    int lo = 0, hi = min(w.nA, w.nB);                    // pairs k < np cross: gA[k] < gB[k]; a prefix
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (gA[w.left + mid] < gB[w.left + mid]) lo = mid + 1; else hi = mid;
+    }
+    const int np = lo;
+    const int ia = gA[w.left + np];
+    wd[s].np = np;
+    wd[s].i = np >= 1 ? min(ia, gB[w.left + np - 1]) : ia;
+}
+__global__ __launch_bounds__(PB_T) void k_pbw_swap(float4* org, const PbWide* __restrict__ wd, uint32_t nsegs, const int* __restrict__ gA,
+                                                   const int* __restrict__ gB) {
+    const uint32_t s = pbw_find(wd, nsegs, (int)blockIdx.x);
+    const PbWide w = wd[s];
+    const int k0 = ((int)blockIdx.x - w.tile0) * PBW_TILE;
+    for (int k = k0 + threadIdx.x; k < min(k0 + PBW_TILE, w.np); k += PB_T) {
+        const int pa = gA[w.left + k], pb = gB[w.left + k];
+        const float4 a = org[pa], b = org[pb];
+        org[pa] = b; org[pb] = a;
+    }
+}
+__global__ void k_pbw_finish(float4* org, PbWide* wd, PbSeg* segs, uint32_t nsegs) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsegs || !wd[s].active) return;
+    PbWide w = wd[s];
+    const float4 a = org[w.i], b = org[w.right];
+    org[w.i] = b; org[w.right] = a;
+    if (w.i >= w.median) w.right = w.i - 1;
+    if (w.i <= w.median) w.left = w.i + 1;
+    wd[s].left = w.left; wd[s].right = w.right;
+    segs[s].left = w.left; segs[s].right = w.right;
+}
+
 // ---- the arrays around the balance -------------------------------------------------------------------------------------
 __global__ void k_pb_org_from_photons(const rt_photon* __restrict__ ph, int64_t n, float4* org) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -617,11 +875,11 @@ hipError_t pb_balance(float4* d_org, int64_t n, int tight, const float lo0[3], c
     const uint32_t cap_big = (uint32_t)(n / PB_SUB + 2), cap_small = (uint32_t)(4 * (n / PB_SUB + 2) + 2);
     DevBuf qa, qb, qs, cnt;
     PBCHK(qa.alloc((size_t)cap_big * sizeof(PbSeg))); PBCHK(qb.alloc((size_t)cap_big * sizeof(PbSeg)));
-    PBCHK(qs.alloc((size_t)cap_small * sizeof(PbSeg))); PBCHK(cnt.alloc(32));
-    PBCHK(hipMemsetAsync(cnt.p, 0, 32, st));
+    PBCHK(qs.alloc((size_t)cap_small * sizeof(PbSeg))); PBCHK(cnt.alloc(64));
+    PBCHK(hipMemsetAsync(cnt.p, 0, 64, st));
     const bool debug = getenv("RT_PB_DEBUG") != nullptr;
     uint32_t* d_cnt = cnt.as<uint32_t>();               // [0] next big, [1] small, [2] overflow
-    PbSeg root; root.index = 1; root.start = 1; root.end = (int32_t)n;
+    PbSeg root; root.index = 1; root.start = root.left = 1; root.end = root.right = (int32_t)n; root.have_box = 0;
     for (int k = 0; k < 3; ++k) { root.lo[k] = lo0[k]; root.hi[k] = hi0[k]; }
     PbCtx g;
     g.org = d_org; g.bal = d_bal; g.plane = d_plane; g.tight = tight;
@@ -632,7 +890,54 @@ hipError_t pb_balance(float4* d_org, int64_t n, int tight, const float lo0[3], c
     if (n > PB_SUB) { PBCHK(hipMemcpyAsync(cur, &root, sizeof root, hipMemcpyHostToDevice, st)); nbig = 1; }
     else { PBCHK(hipMemcpyAsync(qs.p, &root, sizeof root, hipMemcpyHostToDevice, st)); h[1] = 1; PBCHK(hipMemcpyAsync(d_cnt + 1, &h[1], 4, hipMemcpyHostToDevice, st)); }
     PBCHK(hipStreamSynchronize(st));                    // (root lives on the stack)
+    // wide passes' arrays: the two lists (a segment's at its own positions), tile counts / offsets, box partials
+    DevBuf wdesc, gA, gB, tcnt, toff, wpart;
+    bool wide = n > PBW_MIN && !getenv("RT_PB_NO_WIDE");
+    const size_t max_tiles = (size_t)n / PBW_TILE + cap_big + 2;
+    if (wide) {
+        PBCHK(wdesc.alloc((size_t)cap_big * sizeof(PbWide))); PBCHK(gA.alloc(((size_t)n + 2) * 4)); PBCHK(gB.alloc(((size_t)n + 2) * 4));
+        PBCHK(tcnt.alloc(max_tiles * sizeof(int2))); PBCHK(toff.alloc(max_tiles * sizeof(int2)));
+        if (tight) PBCHK(wpart.alloc(max_tiles * 24));
+    }
     while (nbig > 0) {                                  // level by level while segments are larger than PB_SUB
+        if (wide) {
+            PbWide* wd = wdesc.as<PbWide>();
+            uint32_t hw[2] = {0, 0};
+            PBCHK(hipMemsetAsync(d_cnt + 3, 0, 4, st));
+            k_pbw_init<<<(nbig + PB_T - 1) / PB_T, PB_T, 0, st>>>(cur, nbig, tight, wd, d_cnt + 3);
+            PBCHK(hipGetLastError());
+            PBCHK(hipMemcpyAsync(hw, d_cnt + 3, 4, hipMemcpyDeviceToHost, st));
+            PBCHK(hipStreamSynchronize(st));
+            if (hw[0] == 0) wide = false;                // segments only get smaller
+            else {
+                if (tight) {
+                    k_pbw_tiles<<<1, PB_T, 0, st>>>(wd, nbig, d_cnt + 7);
+                    PBCHK(hipMemcpyAsync(hw + 1, d_cnt + 7, 4, hipMemcpyDeviceToHost, st));
+                    PBCHK(hipStreamSynchronize(st));
+                    k_pbw_box_tiles<<<hw[1], PB_T, 0, st>>>(d_org, cur, wd, nbig, wpart.as<float>());
+                    k_pbw_box_reduce<<<nbig, PB_T, 0, st>>>(cur, wd, nbig, wpart.as<float>());
+                    PBCHK(hipGetLastError());
+                }
+                uint32_t iters = 0;
+                for (;;) {
+                    k_pbw_plan<<<(nbig + PB_T - 1) / PB_T, PB_T, 0, st>>>(d_org, wd, nbig);
+                    k_pbw_tiles<<<1, PB_T, 0, st>>>(wd, nbig, d_cnt + 7);
+                    PBCHK(hipMemcpyAsync(hw + 1, d_cnt + 7, 4, hipMemcpyDeviceToHost, st));
+                    PBCHK(hipStreamSynchronize(st));
+                    const uint32_t nt = hw[1];
+                    if (nt == 0) break;
+                    ++iters;
+                    k_pbw_count<<<nt, PB_T, 0, st>>>(d_org, wd, nbig, tcnt.as<int2>());
+                    k_pbw_scan<<<nbig, PB_T, 0, st>>>(wd, nbig, tcnt.as<int2>(), toff.as<int2>());
+                    k_pbw_scatter<<<nt, PB_T, 0, st>>>(d_org, wd, nbig, toff.as<int2>(), gA.as<int>(), gB.as<int>());
+                    k_pbw_pairs<<<(nbig + PB_T - 1) / PB_T, PB_T, 0, st>>>(wd, nbig, gA.as<int>(), gB.as<int>());
+                    k_pbw_swap<<<nt, PB_T, 0, st>>>(d_org, wd, nbig, gA.as<int>(), gB.as<int>());
+                    k_pbw_finish<<<(nbig + PB_T - 1) / PB_T, PB_T, 0, st>>>(d_org, wd, cur, nbig);
+                    PBCHK(hipGetLastError());
+                }
+                if (debug) fprintf(stderr, "[pb] tight=%d segments=%u: %u wide, %u wide passes\n", tight, nbig, hw[0], iters);
+            }
+        }
         g.next = nxt;
         k_pb_big<<<nbig, PB_T, 0, st>>>(g, cur, nbig);
         PBCHK(hipGetLastError());
