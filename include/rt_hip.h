@@ -362,8 +362,9 @@ int rt_photonmap_upload(rt_scene* s, int which, const rt_photon* heap_order, int
 
 /* Replaces PhotonMap::balance (photon.cpp:133-254) for callers that hold an
  * unbalanced array photons[1..n] (as AddPhoton leaves it, photon.cpp:835-885):
- * balances on the host exactly as the reference does, writes the heap order
- * (scaled, see below) back into `photons` and uploads it.                       */
+ * balances exactly as the reference does (on the host, or from 65536 photons up
+ * by the device kernels of rt_photonmap_build_dev: the same bytes), writes the heap
+ * order (scaled, see below) back into `photons` and uploads it.                 */
 int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, float power_scale);
 /* power_scale: ScalePhotonPower(power_scale, 0, n) after the balance as final.cpp:1126 does it, i.e.
  * heap slots 0..n-1 are scaled and slot n keeps its power (photon.cpp:826-833); 1.0f = leave.   */
@@ -373,7 +374,8 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, fl
  * every swap of the reference's quickselect, so photons that tie on a split axis land where the reference puts them --
  * then ScalePhotonPower and the device image.  d_photons[0..n] (slot 0 unused) comes back in the reference's heap order,
  * byte for byte what rt_photonmap_build leaves in its host array.  Synchronises the stream (one read-back per tree level).
- * rt_photonmap_build itself takes this path through a temporary device copy when RT_PHOTON_BUILD=device.            */
+ * rt_photonmap_build itself takes this path through a temporary device copy from 65536 photons up (RT_PHOTON_BUILD=host
+ * or =device forces one or the other).                                                                              */
 int rt_photonmap_build_dev(rt_scene* s, int which, rt_photon* d_photons, int64_t n, float power_scale, void* hip_stream);
 
 /* One build per node (no counterpart: the reference is one process).  With the map replicated on every GPU, one rank

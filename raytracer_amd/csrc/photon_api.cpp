@@ -38,10 +38,14 @@ int check_map(rt_scene* s, int which, int k, const char* fn) {
     return RT_OK;
 }
 
-// RT_PHOTON_BUILD=host|device: where rt_photonmap_build balances and assembles (same bytes either way)
-bool photon_build_on_device() {
+// Where rt_photonmap_build balances and assembles (the same bytes either way, tests/test_gpu_photon.py): on the device
+// (photon_build_dev.hip; 200 M photons 3.1 s against 21.6 s for the host's first heap alone) from 64 K photons up -- below
+// that the host's threads are done before the kernels' launches are.  RT_PHOTON_BUILD=host|device overrides.
+bool photon_build_on_device(int64_t n) {
     const char* e = getenv("RT_PHOTON_BUILD");
-    return e && strcmp(e, "device") == 0;
+    if (e && strcmp(e, "device") == 0) return true;
+    if (e && strcmp(e, "host") == 0) return false;
+    return n >= 65536;
 }
 
 int upload_heap(rt_scene* s, int which, const rt_photon* heap, int64_t n) {
@@ -139,7 +143,7 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, fl
     if (n >= ((int64_t)1 << 31) - 2) return rt_fail(RT_E_LIMIT, "rt_photonmap_build: more than 2^31 photons");
     DeviceGuard g(s->device);
     if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");
-    if (photon_build_on_device()) {                       // the same arrays, built by the kernels of photon_build_dev.hip
+    if (photon_build_on_device(n)) {                       // the same arrays, built by the kernels of photon_build_dev.hip
         void* d = nullptr;
         const size_t bytes = ((size_t)n + 1) * sizeof(rt_photon);
         if (hipMalloc(&d, bytes) != hipSuccess) return rt_fail(RT_E_NOMEM, "hipMalloc(%zu B of photons) failed", bytes);

@@ -312,7 +312,11 @@ def test_device_build_equals_host_build(n, kind):
     a_scene, b_scene = host.Scene(sd), host.Scene(sd)
     src = _tie_map(n, 1000 + n, kind) if kind != "random" else _random_map(n, 1000 + n)
     scale = 0.37
-    h_heap = a_scene.photonmap_build(0, src.copy(), scale)
+    os.environ["RT_PHOTON_BUILD"] = "host"
+    try:
+        h_heap = a_scene.photonmap_build(0, src.copy(), scale)
+    finally:
+        del os.environ["RT_PHOTON_BUILD"]
     d = torch.from_numpy(src.copy().view(np.uint8)).cuda()
     b_scene.photonmap_build_dev(0, d.data_ptr(), n, scale)
     torch.cuda.synchronize()
@@ -333,6 +337,7 @@ def test_host_pointer_build_through_the_device(monkeypatch):
     sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
     a_scene, b_scene = host.Scene(sd), host.Scene(sd)
     src = _tie_map(60_000, 5, "wall")
+    monkeypatch.setenv("RT_PHOTON_BUILD", "host")
     h = a_scene.photonmap_build(0, src.copy(), 1.0)
     monkeypatch.setenv("RT_PHOTON_BUILD", "device")
     dv = b_scene.photonmap_build(0, src.copy(), 1.0)

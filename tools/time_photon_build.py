@@ -34,6 +34,7 @@ def main():
     if want_host:
         a = src.cpu().numpy().view(np.uint8).reshape(-1).view(abi.photon_dtype).copy()
         sc2 = host.Scene(sd)
+        os.environ["RT_PHOTON_BUILD"] = "host"
         t0 = time.perf_counter()
         h = sc2.photonmap_build(0, a, 1.0)
         out["host_build_s"] = round(time.perf_counter() - t0, 4)
