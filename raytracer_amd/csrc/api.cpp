@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -153,13 +154,19 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HostFlatScene flat;
     std::string err;
     int rc;
+    const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tb0 = now();
+    double tb1 = tb0;
     try {
         rc = rt_build_flat_scene(d, &flat, &err);
+        tb1 = now();
         if (!rc) rc = rt_build_bvh(d, &flat, &err);
     } catch (const std::bad_alloc&) {
         return rt_fail(RT_E_NOMEM, "host allocation failed while building the KD-trees");
     }
     if (rc) return rt_fail(rc, "%s", err.c_str());
+    const double tb2 = now();
 
     rt_scene* s = new (std::nothrow) rt_scene();
     if (!s) return rt_fail(RT_E_NOMEM, "host allocation failed");
@@ -237,6 +244,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!rc) rc = upload(s, lfirst, &v.light_sample_first);
     if (!rc) rc = upload(s, ltris, &v.light_tris);
     if (rc) { rt_scene_destroy(s); return rc; }
+    if (timing) fprintf(stderr, "rt_scene_create: reference trees %.2f s, BVH %.2f s, uploads %.2f s\n", tb1 - tb0, tb2 - tb1, now() - tb2);
     v.nlight_samples = (int32_t)(lsamples.size() / 3);
     v.nlight_tris = (int32_t)(ltris.size() / 9);
     v.nnodes = (int32_t)flat.nodes[7].size();
