@@ -128,7 +128,11 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
             RTCHK(s->scratch(P_CAUSTIC, (size_t)n * 12, &caustic));
             RTCHK(s->scratch(P_OCC, (size_t)n * std::max(S, 1), &occ));
             RTCHK(s->scratch(P_CONTRIB, (size_t)n * 12, &contrib));
-            const int64_t gmax = 2 * n * std::max(G, 1);       // room for refraction's two children per gather ray
+            // gather queues: a refracting hit spawns two children per gather ray (TraceIrradiance, photon.cpp:808), once per
+            // level below this one: room for every doubling that IRRADIANCE_MAX_DEPTH still allows (two at depth 0 with the
+            // reference's 3), at most three; deeper settings on glass-heavy scenes end in RT_E_LIMIT below
+            const int doublings = std::min(3, std::max(1, p->irradiance_max_depth - depth - 1));
+            const int64_t gmax = (n * std::max(G, 1)) << doublings;
             RTCHK(s->scratch(P_BSUMS, (size_t)rtk_scan_blocks_needed(std::max(3 * n, 2 * gmax)) * 4 + 16, &bsums));
 
             HIPCHK(rtk_trace_closest(s->view, q_rays, q_sid, n, s->eps_f, s->fast, (rt_hit*)hits, st), "k_trace_closest");

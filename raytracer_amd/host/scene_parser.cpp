@@ -152,8 +152,12 @@ rt_light point_light(const float* pos, const float* col, float intensity) {
     return l;
 }
 
-void parse_chunk(const char* b, const char* e, int flavour, Chunk& c) {
-    Cursor cur{b, e};
+// Parses the statements that START in [b, e): a statement's arguments are read to the end of the text (`file_end`), whatever
+// they look like -- the reference reads a fixed number of tokens after a keyword (hw4.cpp:538-747).  Returns where the next
+// statement would start: the next chunk's cut, if the cut was a true statement start.
+const char* parse_chunk(const char* b, const char* e, const char* file_end, int flavour, Chunk& c) {
+    c = Chunk();
+    Cursor cur{b, file_end};
     Tok t;
     int mat_now = -1;
     bool run_open = false;
@@ -164,7 +168,9 @@ void parse_chunk(const char* b, const char* e, int flavour, Chunk& c) {
         c.prims.insert(c.prims.end(), v12, v12 + 12);
         c.type.push_back(ty);
     };
-    while (cur.next(t)) {
+    for (;;) {
+        if (!cur.next(t)) return file_end;
+        if (t.b >= e) return t.b;
         if (tok_is(t, "T")) {
             float v[12];
             for (int k = 0; k < 9; ++k) v[k] = (float)num();
@@ -285,8 +291,10 @@ int parse_range(const char* b, const char* e, int flavour, int nthreads, rth_sce
     const int64_t len = (int64_t)(e - b);
     int nt = nthreads > 0 ? nthreads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     if (len < (1 << 20)) nt = 1;
-    // cut points: the start of a keyword token (first character a letter, previous character white space), so no
-    // statement is split
+    // cut points: a GUESS at a statement start (a token whose first character is a letter, after white space).  A chunk
+    // reads its statements' arguments past its end, and reports where the next statement starts; where that is not the
+    // next chunk's cut (an argument such as `nan` or `inf` was taken for a keyword) the next chunk is parsed again from
+    // there, so the result is the single-threaded parse whatever nthreads is.
     std::vector<const char*> cut{b};
     for (int i = 1; i < nt; ++i) {
         const char* p = b + len * i / nt;
@@ -296,10 +304,18 @@ int parse_range(const char* b, const char* e, int flavour, int nthreads, rth_sce
     }
     cut.push_back(e);
     std::vector<Chunk> chunks(cut.size() - 1);
+    std::vector<const char*> stop(cut.size() - 1, e);
     std::vector<std::thread> th;
     for (size_t i = 0; i + 1 < cut.size(); ++i)
-        th.emplace_back([&, i] { parse_chunk(cut[i], cut[i + 1], flavour, chunks[i]); });
+        th.emplace_back([&, i] { stop[i] = parse_chunk(cut[i], cut[i + 1], e, flavour, chunks[i]); });
     for (std::thread& t : th) t.join();
+    for (size_t i = 1; i + 1 < cut.size(); ++i) {
+        const char* from = stop[i - 1];
+        if (from == cut[i]) continue;
+        if (from >= cut[i + 1]) { chunks[i] = Chunk(); stop[i] = from; cut[i] = from; continue; }   // swallowed whole
+        cut[i] = from;
+        stop[i] = parse_chunk(from, cut[i + 1], e, flavour, chunks[i]);
+    }
     rth_scene* s = new rth_scene();
     const int rc = stitch(chunks, flavour, s);
     if (rc != RT_OK) { delete s; return rc; }

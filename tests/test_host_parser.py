@@ -102,6 +102,34 @@ def test_threads_do_not_change_the_result(tmp_path):
         same(host.parse_scene_native(text=t3, flavour="hw4", nthreads=nt), ref)
 
 
+def test_arguments_that_look_like_keywords_do_not_split_statements():
+    """the reference reads a fixed number of tokens after a keyword whatever they contain (hw4.cpp:538-747): `nan`, `inf`,
+    junk that atof reads as 0, even a `T` in argument position.  A parallel chunk cut that lands on such a token must not
+    end the statement early: every thread count gives the single-threaded parse (and the Python mirror's)."""
+    sd = synth.mesh_scene(120, 60, seed=4)
+    lines = scene.write_scene_text(sd).splitlines()
+    junk = ["nan", "inf", "Tx", "T", "S", "abc", "M", "-inf"]
+    out = []
+    k = 0
+    for ln in lines:
+        tk = ln.split()
+        if tk and tk[0] == "T" and len(tk) == 13:
+            tk[1 + (k % 12)] = junk[k % len(junk)]              # one argument of every triangle: a letter-led token
+            k += 1
+            ln = " ".join(tk)
+        out.append(ln)
+    txt = "\n".join(out)
+    assert len(txt) > (1 << 20) and k > 10_000
+    one = host.parse_scene_native(text=txt, flavour="hw4", nthreads=1)
+    ref = scene.parse_scene_text(txt, "hw4")
+    assert one.nprim == sd.nprim == ref.nprim
+    assert one.prims.tobytes() == ref.prims.tobytes() or np.array_equal(np.isnan(one.prims), np.isnan(ref.prims))
+    for nt in (2, 3, 8, 16):
+        got = host.parse_scene_native(text=txt, flavour="hw4", nthreads=nt)
+        assert got.nprim == one.nprim and got.prims.tobytes() == one.prims.tobytes()
+        assert list(got.obj_count) == list(one.obj_count) and got.prim_material.tobytes() == one.prim_material.tobytes()
+
+
 def test_binary_cache_round_trip(tmp_path):
     p = os.path.join(GOLD, "monkey.txt")
     c = str(tmp_path / "monkey.rtscene")
