@@ -22,8 +22,9 @@
  *     rt_photon_knn_dev, rt_photon_irradiance_dev / _noalloc_dev, and
  *     rt_render_dev for the primary + shadow frame (rt_params.primary_only, one
  *     sample, no rt_stats).  These synchronise the stream: rt_trace_work_dev
- *     and rt_photonmap_emit_dev (they return counts), rt_render_dev with
- *     rt_stats, and rt_render_dev with recursion (once per depth, to size the
+ *     and rt_photonmap_emit_dev (they return counts), rt_photonmap_build_dev
+ *     (once per tree level and wide pass), rt_photonmap_import_dev, rt_render_dev
+ *     with rt_stats, and rt_render_dev with recursion (once per depth, to size the
  *     next pass by the number of child rays; a frame is 10-100 ms of device
  *     time by then).  The first call of a size also grows the scene's scratch
  *     (hipMalloc; hipFree of the smaller block after a stream synchronise);
