@@ -373,7 +373,7 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     return dict(metric="kNN radiance lookups/s", value=n_queries / (ms * 1e-3), unit="lookups/s",
                 config=dict(workload="synthetic photon map on the Final scene's box walls", photons=n_photons,
                             queries=n_queries, k=k, radius=radius),
-                ms_per_step=ms, heap_build_host_s=build_s, roofline=rf, cpu_baseline=cpu, parity=parity)
+                ms_per_step=ms, map_build_s=build_s, roofline=rf, cpu_baseline=cpu, parity=parity)
 
 
 def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500, tag="mesh_1m", cpu=None):
