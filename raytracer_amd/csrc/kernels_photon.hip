@@ -401,6 +401,168 @@ hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const fl
 #undef KNN_ARGS
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The redo of the few queries the wave-shared kernel flags (exact ties): ONE query per wave, everything wave-uniform.
+// A launch of k_photon_knn over them is as slow as one query, and what one query costs there is not its ~1 400 record
+// fetches but one lane's sift loops over the candidate heap in LDS (~1 000 accepted candidates at r = 1.0, ~100 cycles
+// per dependent LDS access).  Here the reference's arrays np.dist2 / np.index live in REGISTERS across the wave (slot s in
+// lane s % 64, register s / 64), read with v_readlane and written by the owning lane -- a few cycles per access -- and
+// the per-level stash likewise (level l in lane l).  All 64 lanes fetch: when the walk needs a node outside the window,
+// lane L loads the L-th node of the six heap levels below it (addresses need no fetch), so the walker descends up to six
+// levels per memory latency.  Same visits, same order, same statements as `consider` / `locate`: the lists, radius and
+// irradiance are theirs bit for bit (tests/test_gpu_photon.py: ties, lattices, the reference's fixture).
+#define KNN_WIN_LEVELS 6
+#define REDO_S 2                      // slots 0 .. 127: k <= 126
+namespace {
+__device__ __forceinline__ float rl_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float rd_f(const float (&a)[REDO_S], int j) { return rl_f((j >> 6) ? a[1] : a[0], j & 63); }
+__device__ __forceinline__ int rd_i(const int (&a)[REDO_S], int j) { return __builtin_amdgcn_readlane((j >> 6) ? a[1] : a[0], j & 63); }
+__device__ __forceinline__ void wr_f(float (&a)[REDO_S], int j, float v, int lane) {
+    const bool mine = lane == (j & 63);
+    if (j >> 6) a[1] = mine ? v : a[1]; else a[0] = mine ? v : a[0];
+}
+__device__ __forceinline__ void wr_i(int (&a)[REDO_S], int j, int v, int lane) {
+    const bool mine = lane == (j & 63);
+    if (j >> 6) a[1] = mine ? v : a[1]; else a[0] = mine ? v : a[0];
+}
+// photon.cpp:79-128 on the register arrays; every argument is wave-uniform
+__device__ __forceinline__ void consider_uniform(float (&hd)[REDO_S], int (&hi)[REDO_S], int lane, int k, int& found, int& got_heap,
+                                                 float& r2, int index, float dist2) {
+    if (!(dist2 < r2)) return;
+    if (found < k) {
+        ++found;
+        wr_f(hd, found, dist2, lane); wr_i(hi, found, index, lane);
+        return;
+    }
+    int j, parent;
+    if (got_heap == 0) {
+        const int half_found = found >> 1;
+        for (int kk = half_found; kk >= 1; --kk) {
+            parent = kk;
+            const int phot = rd_i(hi, kk);
+            const float dst2 = rd_f(hd, kk);
+            while (parent <= half_found) {
+                j = parent + parent;
+                if (j < found && rd_f(hd, j) < rd_f(hd, j + 1)) ++j;
+                const float dj = rd_f(hd, j);
+                if (dst2 >= dj) break;
+                wr_f(hd, parent, dj, lane); wr_i(hi, parent, rd_i(hi, j), lane);
+                parent = j;
+            }
+            wr_f(hd, parent, dst2, lane); wr_i(hi, parent, phot, lane);
+        }
+        got_heap = 1;
+    }
+    parent = 1; j = 2;
+    while (j <= found) {
+        float dj = rd_f(hd, j);
+        if (j < found) { const float dj1 = rd_f(hd, j + 1); if (dj < dj1) { ++j; dj = dj1; } }
+        if (dist2 > dj) break;
+        wr_f(hd, parent, dj, lane); wr_i(hi, parent, rd_i(hi, j), lane);
+        parent = j; j += j;
+    }
+    wr_i(hi, parent, index, lane); wr_f(hd, parent, dist2, lane);
+    r2 = rd_f(hd, 1);
+}
+}  // namespace
+
+__global__ void __launch_bounds__(64)
+k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
+                  const float* __restrict__ nrm3, int k, float maxDist, float* __restrict__ out_rgb,
+                  const float* __restrict__ tables, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist) {
+    __shared__ float4 win[64];
+    const int lane = threadIdx.x;
+    const int wd = 31 - __builtin_clz((unsigned)lane + 1u);        // this lane's node of a window: level wd, position wj
+    const unsigned wj = (unsigned)lane + 1u - (1u << wd);
+    const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
+    const unsigned nl = *nlist;
+    for (unsigned jq = blockIdx.x; jq < nl; jq += gridDim.x) {
+        const int64_t i = list[jq];
+        const float qx = pos3[3 * i], qy = pos3[3 * i + 1], qz = pos3[3 * i + 2];
+        float hd[REDO_S] = {0.f, 0.f}; int hi[REDO_S] = {0, 0};
+        float st1 = 0.f, st2 = 0.f;                                 // LocatePhoton's dist1 / this node's dist2 per level, level l in lane l
+        float r2 = maxDist * maxDist;                               // np.dist2[0], photon.cpp:405
+        int found = 0, got_heap = 0;
+        bool done = n < 1;
+        unsigned idx = 1, wroot = 0;
+        while (!done) {
+            int d = -1;
+            if (wroot != 0) {
+                d = (31 - __builtin_clz(idx)) - (31 - __builtin_clz(wroot));
+                if (d < 0 || d >= KNN_WIN_LEVELS || (idx >> d) != wroot) d = -1;
+            }
+            if (d < 0) {                                            // re-root the window at the node needed
+                wroot = idx; d = 0;
+                const unsigned long long node = ((unsigned long long)wroot << wd) + wj;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 63 && node <= (unsigned long long)n) win[lane] = *reinterpret_cast<const float4*>(ph + node);
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+            }
+            const float4 rec4 = win[(1u << d) - 1u + (idx - (wroot << d))];
+            const float rx = rl_f(rec4.x, 0), ry = rl_f(rec4.y, 0), rz = rl_f(rec4.z, 0);
+            const int rw = __builtin_amdgcn_readfirstlane(__float_as_int(rec4.w));
+            float d1 = rx - qx;
+            float dist2 = d1 * d1;
+            d1 = ry - qy; dist2 += d1 * d1;
+            d1 = rz - qz; dist2 += d1 * d1;
+            if (idx < uhalf) {
+                const int plane = rw & 3;
+                const float pp = plane == 0 ? rx : (plane == 1 ? ry : rz);
+                const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
+                const float dist1 = qp - pp;
+                const int lvl = 31 - __builtin_clz(idx);
+                st1 = lane == lvl ? dist1 : st1; st2 = lane == lvl ? dist2 : st2;
+                idx = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
+                continue;
+            }
+            int cidx = (int)idx;
+            float cd2 = dist2;
+            for (;;) {
+                consider_uniform(hd, hi, lane, k, found, got_heap, r2, cidx, cd2);
+                if (idx == 1) { done = true; break; }
+                const unsigned child = idx;
+                idx >>= 1;
+                const int lvl = 31 - __builtin_clz(idx);
+                const float dist1 = rl_f(st1, lvl);
+                const unsigned near = (dist1 > 0.0f) ? 2 * idx + 1 : 2 * idx;
+                if (child == near && dist1 * dist1 < r2) { idx = near ^ 1u; break; }
+                cidx = (int)idx; cd2 = rl_f(st2, lvl);
+            }
+        }
+        // CalcIrradiance, photon.cpp:405-441: the sum over np.index[1 .. found] in that order
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (found >= 8) {                                           // literal 8, photon.cpp:411
+            const float nx = nrm3[3 * i], ny = nrm3[3 * i + 1], nz = nrm3[3 * i + 2];
+            const float* cosT = tables; const float* sinT = tables + 256;
+            const float* cosP = tables + 512; const float* sinP = tables + 768;
+            const DevPhotonPow* pw = reinterpret_cast<const DevPhotonPow*>(ph + (n + 1));
+            float wx[REDO_S], wy[REDO_S], wz[REDO_S]; int facing[REDO_S];
+#pragma unroll
+            for (int rr = 0; rr < REDO_S; ++rr) {                   // every lane fetches its own slots' photons ...
+                const int slot = rr * 64 + lane;
+                wx[rr] = wy[rr] = wz[rr] = 0.f; facing[rr] = 0;
+                if (slot >= 1 && slot <= found) {
+                    const int pi = hi[rr];
+                    const unsigned pk = ph[pi].packed;
+                    const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
+                    const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
+                    if ((dx * nx + dy * ny + dz * nz) < 0.0f) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(pw + pi);
+                        wx[rr] = w4.x; wy[rr] = w4.y; wz[rr] = w4.z; facing[rr] = 1;
+                    }
+                }
+            }
+            for (int jj = 1; jj <= found; ++jj) {                   // ... and the additions run in the reference's order
+                if (rd_i(facing, jj)) { r += rd_f(wx, jj); g += rd_f(wy, jj); b += rd_f(wz, jj); }
+            }
+            const float tmp = (float)(((double)1.0f / 3.141592) / (double)r2);   // (1.0f/PI)/(np.dist2[0])
+            r *= tmp; g *= tmp; b *= tmp;
+        }
+        if (lane == 0) { out_rgb[3 * i] = r; out_rgb[3 * i + 1] = g; out_rgb[3 * i + 2] = b; }
+    }
+}
+
 size_t rtk_knn_fast_scratch_bytes(int64_t q) {
     return (((size_t)q + 255) & ~(size_t)255) + 256 + 4 * (((size_t)q + 63) & ~(size_t)63) + rtk_photon_irr_wave_workspace(q);
 }
@@ -424,6 +586,11 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
         if (e != hipSuccess) return e;
         e = rtk_photon_irr_wave(ph, n, half, box6, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, list, nlist, work, d_stats, st);
         if (e != hipSuccess) return e;
+        if (k + 1 <= 64 * REDO_S - 1 && !getenv("RT_KNN_REDO_LDS")) {
+            hipLaunchKernelGGL(k_photon_knn_redo, dim3(2048), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
+                               (const int32_t*)list, (const unsigned*)nlist);
+            return hipGetLastError();
+        }
         return launch_knn<4>(ph, n, half, d_pos3, d_nrm3, q, k, maxDist, 1, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, nullptr, st, list, nlist);
     }
     const unsigned grid = (unsigned)((q + 3) / 4);
