@@ -77,11 +77,24 @@ __device__ __forceinline__ void w_insert(int (&reg)[KMAX], int x) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         if (b + 1 < NB && __ballot(x < reg[(b + 1) * KB - 1]) == 0ull) continue;
+        // reg[s] = min(reg[s], x) IN PLACE, x = max(old reg[s], x), entry after entry.  Written as C the compiler computes
+        // every block into fresh registers and copies them back at the block's end (one v_mov per entry: half as much
+        // again); four entries per asm statement, so that no hazard padding separates them
+        int s = b * KB;
 #pragma unroll
-        for (int s = b * KB; s < (b + 1) * KB; ++s) {
-            const int cur = reg[s];
-            reg[s] = cur < x ? cur : x;
-            x = cur < x ? x : cur;
+        for (; s + 4 <= (b + 1) * KB; s += 4) {
+            int t;
+            asm("v_max_i32_e32 %4, %0, %5\n\tv_min_i32_e32 %0, %0, %5\n\t"
+                "v_max_i32_e32 %5, %1, %4\n\tv_min_i32_e32 %1, %1, %4\n\t"
+                "v_max_i32_e32 %4, %2, %5\n\tv_min_i32_e32 %2, %2, %5\n\t"
+                "v_max_i32_e32 %5, %3, %4\n\tv_min_i32_e32 %3, %3, %4"
+                : "+v"(reg[s]), "+v"(reg[s + 1]), "+v"(reg[s + 2]), "+v"(reg[s + 3]), "=&v"(t), "+v"(x));
+        }
+#pragma unroll
+        for (; s < (b + 1) * KB; ++s) {
+            int carry;
+            asm("v_max_i32_e32 %0, %1, %2\n\tv_min_i32_e32 %1, %1, %2" : "=&v"(carry), "+v"(reg[s]) : "v"(x));
+            x = carry;
         }
     }
 }
