@@ -191,12 +191,13 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     };
     // visit(d2, idx, packed, own, on): one photon per lane; packed carries RT_PH_UNREACHABLE, and theta / phi when `own`
     auto lane_walk = [&](bool start, auto&& bound, auto&& visit, unsigned& steps) {
-        unsigned i = start ? 1u : 0u, last = 1u, pending = 0u;
+        unsigned i = start ? 1u : 0u, pending = 0u;
         while (__ballot(i != 0u) != 0ull) {
             ++steps;
             const bool on = i != 0u;
-            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0;
-            if (on) { const float4* __restrict__ np = nodes64 + 4 * (size_t)i; q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; last = i; }
+            // (a lane that is done reads record 0, which exists and is all zeros: no masked load, no registers to clear)
+            const float4* __restrict__ np = nodes64 + 4 * (size_t)i;
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             const unsigned pk = (unsigned)__float_as_int(q0.w);
             visit(w_dist2(q0, qx, qy, qz), i, pk, true, on);
             const unsigned c0 = 2u * i;
@@ -226,7 +227,6 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
             }
             i = next;
         }
-        (void)last;
     };
 
     // ---- phase 2: the k+1 smallest dist2 of S per lane ---------------------------------------------------------
