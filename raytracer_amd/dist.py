@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 
-def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, device="cpu", stats=None):
+def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, device="cpu", stats=None, keep_on_device=False):
     """The `while (stored < max)` emission loops of final.cpp:1057 / :1090, sharded.
 
     emit_fn(first, count) -> uint8 tensor [n, 40] on `device`: the photons stored by emission indices
@@ -19,7 +19,8 @@ def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, dev
     not depend on `world`: round k hands rank r the indices [(k*world + r)*batch, (k*world + r + 1)*batch),
     the counts and then the (padded) payloads are all-gathered, and every rank appends the blocks in index
     order until `target` photons are there; the first `target` are kept (AddPhoton's capacity test,
-    photon.cpp:837).  Returns (numpy photon_dtype[target], emission indices consumed).
+    photon.cpp:837).  Returns (numpy photon_dtype[target], emission indices consumed); with keep_on_device the first element
+    is a uint8 tensor [target, 40] on `device` instead (the photons never visit the host: rt_photonmap_build_dev takes them).
     """
     import torch
     batch = int(batch or max(4096, -(-target // (4 * world))))
@@ -46,11 +47,14 @@ def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, dev
         for b in blocks:                                      # index order == rank order within a round
             if have >= target:
                 break
-            parts.append(b.cpu().numpy())
+            parts.append(b if keep_on_device else b.cpu().numpy())
             have += b.shape[0]
         rnd += 1
         if rnd * world * batch > 1000 * max(target, 1) + 10 * world * batch:
             raise RuntimeError("photon emission stores (almost) nothing: target unreachable")
+    if keep_on_device:
+        out = torch.cat(parts, dim=0)[:target] if parts else torch.zeros((0, 40), dtype=torch.uint8, device=device)
+        return out.contiguous(), rnd * world * batch
     out = np.concatenate(parts, axis=0)[:target] if parts else np.zeros((0, 40), np.uint8)
     return np.ascontiguousarray(out).view(abi.photon_dtype).reshape(-1), rnd * world * batch
 
@@ -110,12 +114,14 @@ def balance_on_rank0(photons, scale, rank, world, dist, torch, device="cpu"):
     return np.ascontiguousarray(payload.cpu().numpy()).view(abi.photon_dtype).reshape(-1)
 
 
-def build_photon_maps(scene, torch, targets, seed, rank=0, world=1, dist=None, batch=None, every_rank_builds=False):
+def build_photon_maps(scene, torch, targets, seed, rank=0, world=1, dist=None, batch=None, every_rank_builds=False, want_heap=True):
     """Both maps of PhotonMappingImageSynthesis (final.cpp:1047-1129): sharded emission, all-gather, then ONE rank
     balances + scales the array, builds the second heap and uploads (rt_photonmap_build), and broadcasts the map's
     device image to the other ranks' GPUs (rt_photonmap_export_dev / _import_dev) -- the host build is not repeated
     per rank on the same host's cores.  `heap` (the host array in heap order) is returned on rank 0 only.
-    every_rank_builds=True keeps the old shape (each rank builds for itself).  targets = (global, caustic)."""
+    every_rank_builds=True keeps the old shape (each rank builds for itself).  targets = (global, caustic).
+    The photons stay on the device from the emission to the finished map (rt_photonmap_emit_dev -> all-gather ->
+    rt_photonmap_build_dev); `heap` is downloaded only if want_heap (the checks of bench.py / the tests)."""
     from . import host
     out = []
     for which, target in ((abi.RT_PMAP_GLOBAL, targets[0]), (abi.RT_PMAP_CAUSTIC, targets[1])):
@@ -124,12 +130,20 @@ def build_photon_maps(scene, torch, targets, seed, rank=0, world=1, dist=None, b
             continue
         e = host.final_emit_params(which, seed=seed)
         st = {}
-        ph, used = emit_photon_map(gpu_emitter(scene, e, torch), target, rank, world, batch, dist, "cuda", st)
+        ph, used = emit_photon_map(gpu_emitter(scene, e, torch), target, rank, world, batch, dist, "cuda", st, keep_on_device=True)
         scale = float(np.float32(1.0) / np.float32(max(target, 1)))                                               # final.cpp:1126
+
+        def build_here():
+            """slot 0 unused (photon.cpp:852), balance + ScalePhotonPower + image on this rank's GPU; -> host heap or None"""
+            d = torch.zeros((target + 1, 40), dtype=torch.uint8, device="cuda")
+            d[1:] = ph
+            scene.photonmap_build_dev(which, d.data_ptr(), target, power_scale=scale,
+                                      stream=torch.cuda.current_stream().cuda_stream)
+            if not want_heap:
+                return None
+            return np.ascontiguousarray(d.cpu().numpy()).view(abi.photon_dtype).reshape(-1)
         if world == 1 or every_rank_builds:
-            a = np.zeros(target + 1, abi.photon_dtype); a[1:] = ph
-            heap = scene.photonmap_build(which, a, power_scale=scale)
-            out.append(dict(heap=heap, emissions=used, **st))
+            out.append(dict(heap=build_here(), emissions=used, **st))
             continue
         # one build per node: rank 0 balances, builds the second heap and uploads; the others receive its device image
         import ctypes as C
@@ -140,8 +154,7 @@ def build_photon_maps(scene, torch, targets, seed, rank=0, world=1, dist=None, b
 
         def make():
             nonlocal heap
-            a = np.zeros(target + 1, abi.photon_dtype); a[1:] = ph
-            heap = scene.photonmap_build(which, a, power_scale=scale)
+            heap = build_here()
             n, nb = C.c_int64(0), C.c_int64(0)
             abi.check(L.rt_photonmap_image_bytes(scene.h, which, C.byref(n), C.byref(nb)))
             img = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
