@@ -215,6 +215,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!rc) rc = upload(s, flat.loose, &v.loose);
     for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.bvh_nodes[o], &v.bvh_oct[o]);
     v.nbvh = (int32_t)flat.bvh_nodes[0].size();
+    if (!rc && !flat.bvh_c32.empty()) rc = upload(s, flat.bvh_c32, &v.bvh_c32);
     memcpy(v.bvh_root_centre, flat.bvh_root_centre, sizeof v.bvh_root_centre);
     v.bvh_root_rho = v.nbvh > 0 ? flat.bvh_nodes[0][0].rho : 0.f;
     if (v.nbvh > 0)                                    // layout 0 is unmirrored: b = {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z}
@@ -224,6 +225,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     // the ray's own octant; RT_LANE_LAYOUT_MASK=7 restores that)
     v.lane_layout_mask = 0;
     if (const char* e = getenv("RT_LANE_LAYOUT_MASK")) v.lane_layout_mask = atoi(e) & 7;
+    if (v.lane_layout_mask != 0) v.bvh_c32 = nullptr;    // the compact nodes are layout 0's
     if (!rc) {
         void* q = nullptr;
         if (hipMalloc(&q, 64 * RT_RAY_COUNTERS) != hipSuccess) rc = rt_fail(RT_E_NOMEM, "hipMalloc failed");

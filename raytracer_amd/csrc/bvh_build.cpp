@@ -349,6 +349,29 @@ int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err) 
     } else {
         for (int o = 0; o < 8; ++o) B.emit(root, 0, o, croot, flat->bvh_nodes[o]);
     }
+    // compact nodes for the per-lane walks (rt_internal.h: DevBvhNode32)
+    flat->bvh_c32.clear();
+    if (LEAF_MAX <= 7 && !getenv("RT_BVH_NO_C32")) {
+        auto up14 = [](double x) -> uint32_t {                          // smallest 14-bit float (8 exponent, 6 mantissa) >= x >= 0
+            float f = (float)std::min(x, 1e30);
+            if ((double)f < x) f = std::nextafter(f, INFINITY);
+            uint32_t bits; memcpy(&bits, &f, 4);
+            return (bits >> 17) + ((bits & 0x1ffffu) ? 1u : 0u);
+        };
+        const std::vector<DevBvhNode>& src = flat->bvh_nodes[0];
+        flat->bvh_c32.resize(src.size());
+        for (size_t i = 0; i < src.size(); ++i) {
+            const DevBvhNode& n = src[i];
+            DevBvhNode32& c = flat->bvh_c32[i];
+            memcpy(c.b, n.b, sizeof c.b);
+            const bool leaf = (n.meta & 0x100) != 0;
+            c.link = leaf ? (0x80000000u | (uint32_t)n.skip) : (uint32_t)n.skip;
+            const uint32_t s14 = up14((double)n.slack);
+            uint32_t sbits = s14 << 17; float sdec; memcpy(&sdec, &sbits, 4);      // the slack the device will use
+            const uint32_t r14 = up14((double)sdec * (double)n.rho * (1.0 + 1e-6));
+            c.sq = (s14 << 18) | (r14 << 4) | ((leaf ? (uint32_t)(n.meta >> 16) & 7u : 0u) << 1);
+        }
+    }
     for (int k = 0; k < 3; ++k) flat->bvh_root_centre[k] = (float)croot[k];
     if (timing) fprintf(stderr, "rt_build_bvh: reference chains + leaf refs %.2f s, tables %.2f s, SAH build %.2f s, records + 8 layouts %.2f s\n",
                         t1 - t0, t2 - t1, t3 - t2, now() - t3);

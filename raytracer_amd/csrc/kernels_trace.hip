@@ -160,7 +160,8 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
         }
         if (rt_ballot(have) == 0ull) { if (rt_ballot(more) == 0ull) break; continue; }
         int t0, t1;
-        bvh_lane_next_leaf<ANY>(sc, wk, have, best, t0, t1);
+        if (sc.bvh_c32) bvh_lane_next_leaf_c32<ANY>(sc, wk, have, best, t0, t1);
+        else bvh_lane_next_leaf<ANY>(sc, wk, have, best, t0, t1);
         if (have && t0 < t1) { if (bvh_lane_leaf<ANY>(sc, wk, t0, t1, eps_f, use_tmax, best)) occ = true; }
         if (have && wk.i >= sc.nbvh) {
             if (ANY) occluded[idx] = occ ? 1 : 0;

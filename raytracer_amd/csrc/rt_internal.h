@@ -78,6 +78,15 @@ struct DevBvhNode {         // 64 B
     float rho;              // |orig - root centre| + rho >= |orig - v0| + 0.44 (|e1| + |e2|) for every triangle below
 };
 static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode must be 64 bytes");
+// The same nodes (layout 0) in 32 bytes, for the per-lane walks (trace_device.h: bvh_lane_next_leaf): a lane's step is two
+// 16-byte loads of half a line instead of four of a whole one.  No cone: the inflation is slack * d0 + srho with both
+// factors rounded UP to 14 bits (8 exponent, 6 mantissa), srho >= slack * rho -- never less than the 64-byte node gives.
+struct DevBvhNode32 {
+    float b[6];             // {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z}
+    uint32_t link;          // inner: skip; leaf: 0x80000000 | first record in bvh_tris
+    uint32_t sq;            // slack14 << 18 | srho14 << 4 | triangles of a leaf (<= 7) << 1
+};
+static_assert(sizeof(DevBvhNode32) == 32, "DevBvhNode32 must be 32 bytes");
 struct DevRefLeaf { int32_t leaf; int32_t rank; };   // a reference leaf (index in layout 7) holding a triangle, and the
                                                      // reference's visit rank of that record
 
@@ -135,6 +144,7 @@ struct DevSceneView {       // passed by value to kernels
     const DevLoose* loose; int32_t nloose;
     // the build's own hierarchy; nbvh = 0: none
     const DevBvhNode* bvh_oct[8]; int32_t nbvh;
+    const DevBvhNode32* bvh_c32;                       // compact nodes of layout 0 (NULL: leaves of more than 7 triangles)
     float bvh_root_centre[3];           // what DevBvhNode::rho is measured from (the root box's centre, rounded)
     float bvh_root_rho;                 // rho of the root node
     unsigned long long* ray_counter;    // next ray of a k_trace_*_bvh_lanes launch.  The scene owns a ring of RT_RAY_COUNTERS such
@@ -169,6 +179,7 @@ struct HostFlatScene {
     std::vector<DevLeafGroup> leaf_groups;
     std::vector<DevLoose> loose;
     std::vector<DevBvhNode> bvh_nodes[8];      // bvh_build.cpp
+    std::vector<DevBvhNode32> bvh_c32;
     std::vector<DevLeafTri> bvh_tris;
     std::vector<int32_t> bvh_tri_ref;
     std::vector<DevRefLeaf> bvh_ref_leaf;

@@ -736,6 +736,35 @@ __device__ __forceinline__ void bvh_lane_next_leaf(const DevSceneView& sc, BvhLa
         }
     }
 }
+// the same step over the compact nodes (rt_internal.h: DevBvhNode32; needs sc.bvh_c32): two 16-byte loads per node
+template <bool ANY>
+__device__ __forceinline__ void bvh_lane_next_leaf_c32(const DevSceneView& sc, BvhLaneWalk& wk, bool on, const Closest& best, int& t0, int& t1) {
+    t0 = t1 = 0;
+    const int nn = sc.nbvh;
+    const BvhConsts& b = wk.bc;
+    while (on && t0 == t1 && wk.i < nn) {
+        const float4* __restrict__ np = reinterpret_cast<const float4*>(sc.bvh_c32) + 2 * (size_t)wk.i;
+        const float4 q0 = np[0], q1 = np[1];
+        const unsigned link = (unsigned)__float_as_int(q1.z), sq = (unsigned)__float_as_int(q1.w);
+        const float slack = __int_as_float((int)((sq >> 18) << 17)), srho = __int_as_float((int)(((sq >> 4) & 0x3fffu) << 17));
+        const float sl = __builtin_fmaf(slack, b.d0, srho) + b.sl0;
+        const rt_v2f s2 = {-sl, sl};
+        rt_v2f x = {q0.x, q0.y}, y = {q0.z, q0.w}, z = {q1.x, q1.y};
+        x = x + s2; y = y + s2; z = z + s2;
+        x.x = __builtin_fmaf(x.x, b.rx, b.px); x.y = __builtin_fmaf(x.y, b.rx, b.px);
+        y.x = __builtin_fmaf(y.x, b.ry, b.py); y.y = __builtin_fmaf(y.y, b.ry, b.py);
+        z.x = __builtin_fmaf(z.x, b.rz, b.pz); z.y = __builtin_fmaf(z.y, b.rz, b.pz);
+        const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
+        const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
+        const bool hit = !(ex < en || ex < 0.0f || en * b.dlen > (ANY ? wk.far_limit : best.len));
+        const bool leaf = (link >> 31) != 0;
+        if (!hit) wk.i = leaf ? wk.i + 1 : (int)link;
+        else {
+            wk.i = wk.i + 1;
+            if (leaf) { t0 = (int)(link & 0x7fffffffu); t1 = t0 + (int)((sq >> 1) & 7u); }
+        }
+    }
+}
 // the triangles [t0, t1) of the lane's leaf; any-hit: returns true (and ends the walk) when one occludes
 template <bool ANY>
 __device__ __forceinline__ bool bvh_lane_leaf(const DevSceneView& sc, BvhLaneWalk& wk, int t0, int t1, float eps_f, bool use_tmax, Closest& best) {
