@@ -121,26 +121,51 @@ k_shade_lights(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* _
     contrib[3 * i] = cr; contrib[3 * i + 1] = cg; contrib[3 * i + 2] = cb;
 }
 
-// Ordered per-pixel accumulation: the first ray of each run of equal pixel ids adds the run.
+// Ordered per-pixel accumulation: the first ray of each run of equal pixel ids adds the run, in index order (the same
+// additions in the same order whatever the launch shape, so frames are byte-identical under tiling and chunking).  The
+// block's 256 contributions and pixel ids are staged in LDS by coalesced loads, so a run leader's serial sum reads LDS,
+// eight contributions at a time, not one dependent global round trip per sample; the part of a run that lies beyond the
+// block is read from global memory as before.
 extern "C" __global__ void __launch_bounds__(256)
 k_accumulate(const int32_t* __restrict__ pix, const float* __restrict__ contrib, int64_t n, float* __restrict__ accum) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int p = pix[i];
-    if (p < 0 || (i > 0 && pix[i - 1] == p)) return;
+    __shared__ float s_c[3 * 256];
+    __shared__ int32_t s_p[256];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 256;
+    const int64_t i = base + tid;
+    const int p = i < n ? pix[i] : -1;
+    s_p[tid] = p;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int64_t k = 3 * base + t * 256 + tid;
+        if (k < 3 * n) s_c[t * 256 + tid] = contrib[k];
+    }
+    __syncthreads();
+    if (p < 0) return;
+    if (tid > 0 ? s_p[tid - 1] == p : (i > 0 && pix[i - 1] == p)) return;
     float r = accum[3 * (size_t)p], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
-    int64_t j = i;
-    // the same additions in the same order, eight contributions fetched at a time (a run of 64 samples is otherwise 64
-    // dependent round trips of one lane): equal pixel ids are contiguous, so pix[j + 7] == p covers the seven before it
-    while (j + 7 < n && pix[j + 7] == p) {
+    int t = tid;
+    while (t + 7 < 256 && s_p[t + 7] == p) {       // equal pixel ids are contiguous: s_p[t + 7] == p covers the seven before it
         float c[24];
 #pragma unroll
-        for (int t = 0; t < 24; ++t) c[t] = contrib[3 * j + t];
+        for (int u = 0; u < 24; ++u) c[u] = s_c[3 * t + u];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { r += c[3 * t]; g += c[3 * t + 1]; b += c[3 * t + 2]; }
-        j += 8;
+        for (int u = 0; u < 8; ++u) { r += c[3 * u]; g += c[3 * u + 1]; b += c[3 * u + 2]; }
+        t += 8;
     }
-    for (; j < n && pix[j] == p; ++j) { r += contrib[3 * j]; g += contrib[3 * j + 1]; b += contrib[3 * j + 2]; }
+    for (; t < 256 && s_p[t] == p; ++t) { r += s_c[3 * t]; g += s_c[3 * t + 1]; b += s_c[3 * t + 2]; }
+    if (t == 256) {                                // the run goes on in the next block(s)
+        int64_t j = base + 256;
+        while (j + 7 < n && pix[j + 7] == p) {
+            float c[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) c[u] = contrib[3 * j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { r += c[3 * u]; g += c[3 * u + 1]; b += c[3 * u + 2]; }
+            j += 8;
+        }
+        for (; j < n && pix[j] == p; ++j) { r += contrib[3 * j]; g += contrib[3 * j + 1]; b += contrib[3 * j + 2]; }
+    }
     accum[3 * (size_t)p] = r; accum[3 * (size_t)p + 1] = g; accum[3 * (size_t)p + 2] = b;
 }
 
