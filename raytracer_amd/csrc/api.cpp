@@ -262,6 +262,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (const char* e = getenv("RT_FUSED_PRIMARY")) s->fused_primary = atoi(e) != 0;
     if (const char* e = getenv("RT_LANE_DEPTH")) s->lane_depth = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("RT_RAY_SORT")) s->ray_sort = atoi(e) != 0;
+    if (const char* e = getenv("RT_RENDER_OVERLAP")) s->overlap_shadow = atoi(e) != 0;
     if (const char* e = getenv("RT_KNN")) s->knn_fast = (strcmp(e, "strict") == 0) ? 0 : 1;
 
     rt_scene_info& inf = s->info;
@@ -281,6 +282,7 @@ int rt_scene_destroy(rt_scene* s) {
     for (int i = 0; i < RT_NSCRATCH; ++i) if (s->scratch_ptr[i]) (void)hipFree(s->scratch_ptr[i]);
     for (int w = 0; w < 2; ++w) if (s->pmap[w].d_photons) (void)hipFree(s->pmap[w].d_photons);
     if (s->d_tiles_cache) (void)hipFree(s->d_tiles_cache);
+    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
     delete s;
     return RT_OK;
 }

@@ -419,8 +419,13 @@ static inline hipError_t next_ray_counter(DevSceneView& sc, hipStream_t st) {
     sc.ray_counter = sc.ray_counter + 8 * (size_t)(seq.fetch_add(1) % RT_RAY_COUNTERS);
     return hipMemsetAsync(sc.ray_counter, 0, sizeof(unsigned long long), st);
 }
-static inline unsigned lanes_grid(int64_t n) {
-    static const int64_t cap = [] { const char* e = getenv("RT_LANE_WAVES"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)8192; }();
+// waves of a refilling kernel: never more than the rays need.  Fewer resident walks than the chip can hold are faster --
+// every walk in flight is a stream of scattered line requests and a share of L2 (1 M-triangle mesh, 1080p x 64 spp:
+// 8 192 waves 116.2 ms per frame, 4 096 waves 113.0); a frame that runs two such kernels side by side (render.cpp) asks
+// for 3 072 each through sc.lane_waves.  RT_LANE_WAVES overrides both.
+static inline unsigned lanes_grid(const DevSceneView& sc, int64_t n) {
+    static const int64_t forced = [] { const char* e = getenv("RT_LANE_WAVES"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)0; }();
+    const int64_t cap = forced ? forced : sc.lane_waves > 0 ? (int64_t)sc.lane_waves : (int64_t)4096;
     const int64_t w = (n + 63) / 64;
     return (unsigned)(w < cap ? w : cap);
 }
@@ -438,7 +443,7 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
+            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
         }
         hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, lanes, d_out);
         return hipGetLastError();
@@ -460,7 +465,7 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
+            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
         }
         hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, lanes, d_occ);
         return hipGetLastError();

@@ -14,9 +14,10 @@ namespace {
 
 enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
-    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE, S_ORDER_C, S_ORDER_A
+    S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE, S_ORDER_C, S_ORDER_A,
+    S_HITS1, S_SRAYS1, S_SACTIVE1
 };
-static_assert(S_ORDER_A < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_SACTIVE1 < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -113,9 +114,9 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;      // per-kernel event pairs: [closest begin, closest end, any begin, any end] per pass
     std::vector<char> pass_lane;      // per pass: traced by the per-lane kernels
-    auto mark = [&](void) -> int {
+    auto mark = [&](hipStream_t on) -> int {
         if (!stats) return RT_OK;
-        hipError_t err; hipEvent_t e = bag.mark(st, &err);
+        hipError_t err; hipEvent_t e = bag.mark(on, &err);
         if (!e) return rt_hipfail(err, "event");
         kev.push_back(e);
         return RT_OK;
@@ -142,11 +143,11 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         void* pairs = nullptr;
         if (stats) RTCHK(s->scratch(S_PAIRS, (size_t)nblocks * 8 + 16, &pairs));
         ++passes; pass_n.push_back(n0); pass_lane.push_back(0);
-        RTCHK(mark());
+        RTCHK(mark(st));
         HIPCHK(rtk_primary_only(s->view, *cam, c_tiles, ctiles, s->eps_f, p->ambient_intensity, p->background, d_rgb8, d_hit_ids,
                                 s->d_radiance_out, (unsigned int*)pairs, s->fast == 3 ? 1 : 0, p->packed_output ? tile0 * 64 : -1, st),
                "k_primary_only");
-        RTCHK(mark()); RTCHK(mark()); RTCHK(mark());
+        RTCHK(mark(st)); RTCHK(mark(st)); RTCHK(mark(st));
         if (stats) HIPCHK(rtk_reduce_pairs((const unsigned int*)pairs, nblocks, d_ctr, st), "k_reduce_pairs");
         continue;
     }
@@ -168,15 +169,30 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const int32_t* q_pix = (const int32_t*)pix0;
     const float* q_nr = nullptr;         // NULL = start_nr ... handled below
     int64_t n = n0;
+    // The shadow half of a pass (any hit -> lights -> accumulate) does not feed the next pass: the children come from the
+    // closest hits alone.  It runs on the scene's second stream, beside the next pass's closest-hit traversal -- the deep
+    // passes of an incoherent frame are a few long walks each and leave most of the chip idle.  The hits and
+    // the shadow rays alternate between two buffers; a queue is rewritten only after the shadow half that reads it is done.
+    // Accumulation stays in pass order on that one stream, so the frame's bytes do not change.
+    const bool overlap = s->overlap_shadow && L > 0 && !d_work && !s->ray_sort && !p->primary_only && p->max_depth > 0;
+    hipStream_t sb = st;
+    if (overlap) {
+        if (!s->aux_stream) HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking), "hipStreamCreate");
+        sb = s->aux_stream;
+    }
+    DevSceneView view = s->view;
+    if (overlap) view.lane_waves = 3072;                 // two per-lane kernels side by side (kernels_trace.hip: lanes_grid)
+    hipEvent_t b_prev = nullptr, b_last = nullptr;      // the shadow half of the previous / the latest pass is done
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
         const int pass_mode = ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast;   // RT_OPT_LANE_DEPTH
         ++passes; pass_n.push_back(n); pass_lane.push_back(pass_mode == 2 ? 1 : 0);
         const bool spawn = !p->primary_only && depth < p->max_depth;
+        const bool odd = overlap && (depth & 1);
         void *hits, *srays, *sact, *occ, *contrib, *flags = nullptr, *bsums = nullptr, *pairs;
         RTCHK(s->scratch(S_PAIRS, (size_t)((n + 255) / 256) * 8 + 16, &pairs));
-        RTCHK(s->scratch(S_HITS, (size_t)n * sizeof(rt_hit), &hits));
-        RTCHK(s->scratch(S_SRAYS, (size_t)n * L * sizeof(rt_ray), &srays));
-        RTCHK(s->scratch(S_SACTIVE, (size_t)n * L * 4, &sact));
+        RTCHK(s->scratch(odd ? S_HITS1 : S_HITS, (size_t)n * sizeof(rt_hit), &hits));
+        RTCHK(s->scratch(odd ? S_SRAYS1 : S_SRAYS, (size_t)n * L * sizeof(rt_ray), &srays));
+        RTCHK(s->scratch(odd ? S_SACTIVE1 : S_SACTIVE, (size_t)n * L * 4, &sact));
         RTCHK(s->scratch(S_OCC, (size_t)n * L, &occ));
         RTCHK(s->scratch(S_CONTRIB, (size_t)n * 12, &contrib));
         if (spawn) {
@@ -186,25 +202,30 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         // per-lane passes: rays go to lanes in spatial / octant order (RT_OPT_RAY_SORT); the sort is timed with the pass
         const bool sorted = pass_mode == 2 && s->ray_sort && s->view.nbvh > 0 && (s->fast == 1 || s->fast == 3);
         const int32_t* order_c = nullptr; const int32_t* order_a = nullptr;
-        RTCHK(mark());
+        RTCHK(mark(st));
         if (sorted) {
             void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
             HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st), "ray order");
         }
-        HIPCHK(rtk_trace_closest(s->view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c), "k_trace_closest");
-        RTCHK(mark());
+        HIPCHK(rtk_trace_closest(view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c), "k_trace_closest");
+        RTCHK(mark(st));
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
                                (uint8_t*)hitany, d_ctr, (unsigned int*)pairs, q_code, p->seed, p->light_radius, st), "k_shade_flags");
-        RTCHK(mark());
+        if (overlap) {
+            hipError_t err; hipEvent_t e = bag.mark(st, &err);
+            if (!e) return rt_hipfail(err, "event");
+            HIPCHK(hipStreamWaitEvent(sb, e, 0), "hipStreamWaitEvent");
+        }
+        RTCHK(mark(sb));
         if (L > 0) {
             if (sorted) {
                 void* ow; RTCHK(s->scratch(S_ORDER_A, rtk_ray_order_workspace(n * L), &ow));
-                HIPCHK(rtk_ray_order((const rt_ray*)srays, (const int32_t*)sact, n * L, s->bvh_lo, s->bvh_hi, ow, &order_a, st), "ray order");
+                HIPCHK(rtk_ray_order((const rt_ray*)srays, (const int32_t*)sact, n * L, s->bvh_lo, s->bvh_hi, ow, &order_a, sb), "ray order");
             }
-            HIPCHK(rtk_trace_any(s->view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, st, order_a), "k_trace_any");
+            HIPCHK(rtk_trace_any(view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, sb, order_a), "k_trace_any");
         }
-        RTCHK(mark());
+        RTCHK(mark(sb));
         if (d_work) {
             unsigned long long* dw = d_work + (pass_mode == 2 ? 8 : 0);
             HIPCHK(rtk_trace_work(s->view, q_rays, q_pix, nullptr, n, s->eps_f, s->fast, 0, dw, st), "k_trace_work");
@@ -213,10 +234,16 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
                                       dw + 4, st), "k_trace_work");
         }
         HIPCHK(rtk_shade_lights(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, n, (const uint8_t*)occ,
-                                p->ambient_intensity, cam->center, (float*)contrib, d_ctr, st), "k_shade_lights");
-        HIPCHK(rtk_accumulate(q_pix, (const float*)contrib, n, (float*)accum, st), "k_accumulate");
+                                p->ambient_intensity, cam->center, (float*)contrib, d_ctr, sb), "k_shade_lights");
+        HIPCHK(rtk_accumulate(q_pix, (const float*)contrib, n, (float*)accum, sb), "k_accumulate");
+        if (overlap) {
+            hipError_t err; b_last = bag.mark(sb, &err);
+            if (!b_last) return rt_hipfail(err, "event");
+        }
         if (!spawn) break;
-        // children -> the other queue
+        // children -> the other queue, which the shadow half of the previous pass may still be reading
+        if (b_prev) HIPCHK(hipStreamWaitEvent(st, b_prev, 0), "hipStreamWaitEvent");
+        b_prev = b_last;
         const bool toA = (depth % 2) == 0;
         void *orays, *opix, *ow, *onr;
         RTCHK(s->scratch(toA ? S_QA_RAYS : S_QB_RAYS, (size_t)n * 2 * sizeof(rt_ray), &orays));
@@ -243,6 +270,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         q_code = (const uint32_t*)ocode;
         n = (int64_t)total;
     }
+    if (b_last) HIPCHK(hipStreamWaitEvent(st, b_last, 0), "hipStreamWaitEvent");       // the frame needs every pass's sum
     HIPCHK(rtk_finalize(pixlist, nslots, (const float*)accum, (const uint8_t*)hitany, p->background, d_rgb8,
                         p->packed_output ? tile0 * 64 : -1, st), "k_finalize");
     if (s->d_radiance_out) HIPCHK(rtk_copy_radiance(pixlist, nslots, (const float*)accum, s->d_radiance_out, st), "k_copy_radiance");

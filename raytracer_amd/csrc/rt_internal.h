@@ -150,6 +150,7 @@ struct DevSceneView {       // passed by value to kernels
     unsigned long long* ray_counter;    // next ray of a k_trace_*_bvh_lanes launch.  The scene owns a ring of RT_RAY_COUNTERS such
                                         // words, 64 B apart; every launch takes the next one and zeroes it on its stream, so two
                                         // launches in flight (other streams, or back to back) never claim from the same word
+    int32_t lane_waves;                 // waves of a refilling per-lane kernel (0 = the default, kernels_trace.hip: lanes_grid)
     int32_t lane_layout_mask;           // per-lane walks use layout (octant & mask): 0 = one layout for all (default), 7 = the ray's own octant
     const DevLeafTri* bvh_tris;         // every tree triangle once; .rank = its index t into bvh_tri_ref
     const int32_t* bvh_tri_ref;         // [t][2]: first, count into bvh_ref_leaf

@@ -30,6 +30,8 @@ struct rt_scene {
     int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
     int ray_sort = 0;                 // rt_render: per-lane passes hand rays to lanes in (cell, octant, Morton) order (RT_OPT_RAY_SORT;
                                       // measured slower on BASELINE configuration 3, DESIGN 4.1c, so off by default)
+    int overlap_shadow = 1;           // rt_render: the shadow half of a pass on a second stream beside the next pass (RT_RENDER_OVERLAP=0: off)
+    hipStream_t aux_stream = nullptr; // that stream, created by the first frame that uses it
     float bvh_lo[3] = {0, 0, 0}, bvh_hi[3] = {0, 0, 0};   // box of the tree triangles (the grid of the ray-order keys)
     int fast = 3;                     // traversal: 3 = the build's own BVH (default), 1 = the reference's tree, ordered + culled
                                       // (4.1b), 2 = the same per lane, 0 = strict reference order
