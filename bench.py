@@ -458,6 +458,13 @@ def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
     for _ in range(2):
         abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), sp))
     rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
+    frame_ms = st.kernel_ms
+    # the per-kernel times of the roofline come from one more frame with every kernel on one stream: in the timed frame the
+    # shadow half of a pass shares the chip with the next pass's closest-hit kernel, and two kernels side by side time each other
+    abi.check(gs.L.rt_scene_set_option(gs.h, abi.RT_OPT_RENDER_OVERLAP, 0))
+    abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), sp))
+    one_stream_ms = st.kernel_ms
+    abi.check(gs.L.rt_scene_set_option(gs.h, abi.RT_OPT_RENDER_OVERLAP, 1))
     stw = render_work(gs, cam, p, sp, torch)
     # the frame's traversal time by kernel family; the roofline goes to the largest
     fam = {
@@ -476,7 +483,9 @@ def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
     per_lane = kernel.endswith("_lanes")
     rf = make_roofline("drt_1m", kernel, ms / launches, krays / launches, alg / launches,
                        (alg if per_lane else wave) / launches,     # per-lane kernels: every lane fetches its own records
-                       launches_per_frame=launches, ms_per_frame_in_this_kernel=ms,
+                       launches_per_frame=launches, ms_per_frame_in_this_kernel=ms, frame_ms_on_one_stream=one_stream_ms,
+                       time_is="HIP events around the kernel's launches in a frame with every kernel on one stream "
+                               "(RT_OPT_RENDER_OVERLAP 0); `value` is the two-stream frame",
                        box_tests_per_ray=work[0] / max(1, krays), tri_records_per_ray=work[1] / max(1, krays),
                        traversal_ms_by_kernel={k: v[0] for k, v in fam.items()})
     # CPU baseline + parity sample: the oracle's restatement of the same samplers on a small frame, and the GPU on that frame
@@ -495,8 +504,8 @@ def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
                   parity_sample_ok=bool(np.array_equal(gids, oids) and (d > 1).sum() <= 0.005 * cres[0] * cres[1]),
                   note="parity unpinned: the samplers are build-defined, the checker is the oracle's restatement of them")
     gs.close()
-    return dict(metric="Mrays/s (distributed ray tracing, all ray types)", value=rays / (st.kernel_ms * 1e-3) / 1e6, unit="Mrays/s",
-                ms_per_frame=st.kernel_ms, passes=st.passes,
+    return dict(metric="Mrays/s (distributed ray tracing, all ray types)", value=rays / (frame_ms * 1e-3) / 1e6, unit="Mrays/s",
+                ms_per_frame=frame_ms, passes=st.passes,
                 config=dict(workload=f"synthetic mesh, {sd.nprim} triangles, {res[0]}x{res[1]}, {spp} spp, lens 0.01 / focus 1.3, "
                                      "light ball 0.5, glossy 0.05, reflect 0.3 (sphere) / 0.5 (floor), depth <= 10"),
                 rays=dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract),

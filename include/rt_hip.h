@@ -30,7 +30,10 @@
  *     (hipMalloc; hipFree of the smaller block after a stream synchronise);
  *   - one host thread AND one stream per rt_scene at a time: the scene's
  *     scratch blocks are shared by its calls, so two calls on the same scene
- *     must be ordered on one stream (or by events).  The reference is
+ *     must be ordered on one stream (or by events).  rt_render_dev with
+ *     recursion also uses a stream of the scene's own for the shadow half of
+ *     every pass; it forks from and joins the caller's stream by events inside
+ *     the call, so the caller sees one stream (RT_RENDER_OVERLAP=0: off).  The reference is
  *     single-threaded with global state (hw4.cpp:49-66); different scenes may
  *     be used from different threads and streams.
  */
@@ -277,6 +280,12 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
  * finer Morton bits -- instead of queue order (one radix sort of (key, index) pairs per pass; rays are not moved and
  * every result lands in the ray's own slot, so frames are the same bytes either way).  RT_RAY_SORT=0|1.                */
 #define RT_OPT_RAY_SORT 6
+/* RT_OPT_RENDER_OVERLAP (default 1; no counterpart): rt_render with recursion runs the shadow half of every pass (any hit,
+ * lights, accumulate) on a stream of the scene's own, beside the next pass's closest-hit traversal; forked from and joined
+ * to the caller's stream by events, per-pixel additions in the same order, so frames are the same bytes either way.
+ * 0 = every kernel on the caller's stream (also what rt_stats' per-kernel times should be read from: kernels that share
+ * the chip time each other).  RT_RENDER_OVERLAP=0|1.                                                                     */
+#define RT_OPT_RENDER_OVERLAP 7
 /* Algorithm of the radiance estimate (rt_photon_irradiance*, the photon renderer) and of rt_photon_knn_set:
  *   RT_KNN_STRICT  LocatePhoton's array / heap code statement by statement, one query per lane: np.index in the
  *                  reference's order, irradiance summed in that order (bit-identical to the reference).

@@ -22,6 +22,7 @@ RT_OPT_LANE_DEPTH = 3
 RT_OPT_KNN_STATS = 4
 RT_OPT_FUSED_PRIMARY = 5
 RT_OPT_RAY_SORT = 6
+RT_OPT_RENDER_OVERLAP = 7
 RT_NOALLOC_MAX_QUERIES = 262144
 RT_E_INVALID, RT_E_NODEVICE, RT_E_NOMEM, RT_E_LIMIT, RT_E_STATE, RT_E_HIP = -1, -2, -3, -4, -5, -6
 

@@ -44,7 +44,10 @@ int rt_scene::dev_alloc(void** p, size_t bytes) {
 int rt_scene::scratch(int slot, size_t bytes, void** p) {
     if (slot < 0 || slot >= RT_NSCRATCH) return rt_fail(RT_E_INVALID, "bad scratch slot");
     if (scratch_cap[slot] < bytes) {
-        if (scratch_ptr[slot]) (void)hipFree(scratch_ptr[slot]);
+        if (scratch_ptr[slot]) {                       // nothing in flight on the caller's or the scene's second stream may still use it
+            (void)hipDeviceSynchronize();
+            (void)hipFree(scratch_ptr[slot]);
+        }
         scratch_ptr[slot] = nullptr; scratch_cap[slot] = 0;
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&scratch_ptr[slot], want);
@@ -304,6 +307,7 @@ int rt_scene_set_option(rt_scene* s, int option, int value) {
     if (option == RT_OPT_LANE_DEPTH && value >= 0) { s->lane_depth = value; return RT_OK; }
     if (option == RT_OPT_FUSED_PRIMARY && (value == 0 || value == 1)) { s->fused_primary = value; return RT_OK; }
     if (option == RT_OPT_RAY_SORT && (value == 0 || value == 1)) { s->ray_sort = value; return RT_OK; }
+    if (option == RT_OPT_RENDER_OVERLAP && (value == 0 || value == 1)) { s->overlap_shadow = value; return RT_OK; }
     if (option == RT_OPT_KNN_STATS && (value == 0 || value == 1)) {
         DeviceGuard g(s->device);
         if (!g.ok) return rt_fail(RT_E_NODEVICE, "hipSetDevice failed");

@@ -344,3 +344,37 @@ def test_ray_sort_option_changes_no_byte(monkey_sd):
     assert np.array_equal(base, srt) and np.array_equal(ids, ids2)
     assert (st.rays_reflect, st.rays_shadow) == (st2.rays_reflect, st2.rays_shadow) and st.rays_reflect > 10000
     g.close()
+
+
+def test_two_stream_frame_equals_one_stream_frame():
+    """RT_OPT_RENDER_OVERLAP: the shadow half of every pass on the scene's second stream beside the next pass's closest-hit
+    traversal (render.cpp) is an order of execution, not of additions -- frame, hit ids and ray counts are the same bytes as
+    with every kernel on one stream; twice in a row (the buffers of the last passes are reused by the next frame's first),
+    with and without the samplers, and through the caller's own stream"""
+    import torch
+    from raytracer_amd import synth
+    res = (232, 120)
+    sd = synth.mesh_scene(120, 80, reflect=0.3)            # mirror floor under a reflecting mesh: every depth has rays
+    g = host.Scene(sd)
+    cam = host.camera_for(sd, res)
+    for kw in (dict(spp=6, light_radius=0.3, glossy=0.1, lens_radius=0.01, focal_distance=1.2, seed=4), dict()):
+        p = host.default_params("hw4", **kw)
+        abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_RENDER_OVERLAP, 0))
+        one, ids1, st1 = g.render(cam, p, want_ids=True)
+        abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_RENDER_OVERLAP, 1))
+        for _ in range(2):
+            two, ids2, st2 = g.render(cam, p, want_ids=True)
+            assert np.array_equal(one, two) and np.array_equal(ids1, ids2)
+            assert (st1.rays_primary, st1.rays_reflect, st1.rays_refract, st1.rays_shadow, st1.passes) == \
+                   (st2.rays_primary, st2.rays_reflect, st2.rays_refract, st2.rays_shadow, st2.passes)
+        assert st1.passes >= 6
+        # on a stream of the caller's, no rt_stats: frames queued back to back
+        side = torch.cuda.Stream()
+        frame = torch.zeros(res[0] * res[1] * 3, dtype=torch.uint8, device="cuda")
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                abi.check(g.L.rt_render_dev(g.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, None, C.c_void_p(side.cuda_stream)))
+        side.synchronize()
+        assert np.array_equal(frame.cpu().numpy().reshape(one.shape), one)
+    g.close()
+

@@ -30,6 +30,9 @@ elif what == "knn_10m":
     r = bench.knn_secondary(gs, torch, 10_000_000, 1920 * 1080, steps=2, with_cpu=False)
     print("knn_10m", r["value"], r["ms_per_step"])
 elif what == "drt_1m":
+    # every kernel on one stream, as in the frame bench.py takes the roofline's kernel times from: side by side on two
+    # streams (the default, profiles/r02_timeline_drt_1m.txt) kernels time each other
+    os.environ.setdefault("RT_RENDER_OVERLAP", "0")
     r = bench.drt_secondary(torch, 0)
     print("drt_1m", r["value"], r["ms_per_frame"])
 elif what == "photon_frame":
