@@ -120,19 +120,29 @@ __device__ __forceinline__ void bvh_lanes(const DevSceneView& sc, const rt_ray* 
     wk.r = Rayf{0, 0, 0, 0, 0, 1};
     wk.bc = BvhConsts{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+    // Claims: the launch's rays are eight contiguous ranges with a counter each; a wave starts in the range of its
+    // workgroup's label (blockIdx & 7: workgroups with one label share an XCD, hence an L2) and moves on to the next range
+    // when its own is used up, so the rays an L2 serves at one time come from one part of the queue (= of the image) while
+    // no wave runs out of work before the launch does.  A label, not a promise: any placement gives the same results.
+    int cur = (int)(blockIdx.x & 7u), spent = 0;
     for (;;) {
         const unsigned long long need = rt_ballot(!have && more);
         if (need != 0ull) {
             const int first = __builtin_ctzll(need);
+            const int64_t lo = (n * cur) >> 3, hi = (n * (cur + 1)) >> 3;
             unsigned long long base = 0;
-            if (lane == first) base = atomicAdd(sc.ray_counter, (unsigned long long)__builtin_popcountll(need));
+            if (lane == first) base = atomicAdd(sc.ray_counter + cur, (unsigned long long)__builtin_popcountll(need));
             base = __shfl(base, first, 64);
+            if ((int64_t)base >= hi - lo) {                         // this range is used up (wave-uniform)
+                cur = (cur + 1) & 7;
+                if (++spent == 8) more = false;
+            }
             if (!have && more) {
                 // `order` (rtk_ray_order): the k-th claim takes ray order[k], so that the rays a wave holds at one time start
                 // in one region with one octant; results still go to the ray's own slot
-                const int64_t claim = (int64_t)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
-                const int64_t my = (claim < n && order != nullptr) ? (int64_t)order[claim] : claim;
-                if (claim >= n) more = false;
+                const int64_t claim = lo + (int64_t)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
+                const int64_t my = (claim < hi && order != nullptr) ? (int64_t)order[claim] : claim;
+                if (claim >= hi) { }                                // beyond the range: claim again next time round
                 else if (active != nullptr && active[my] < 0) {
                     if (ANY) occluded[my] = 0;
                     else {
@@ -417,7 +427,7 @@ static inline int bvh_lanes_usable(const DevSceneView& sc) {
 static inline hipError_t next_ray_counter(DevSceneView& sc, hipStream_t st) {
     static std::atomic<unsigned> seq{0};
     sc.ray_counter = sc.ray_counter + 8 * (size_t)(seq.fetch_add(1) % RT_RAY_COUNTERS);
-    return hipMemsetAsync(sc.ray_counter, 0, sizeof(unsigned long long), st);
+    return hipMemsetAsync(sc.ray_counter, 0, 8 * sizeof(unsigned long long), st);       // the eight range counters of bvh_lanes
 }
 // waves of a refilling kernel: never more than the rays need.  Fewer resident walks than the chip can hold are faster --
 // every walk in flight is a stream of scattered line requests and a share of L2 (1 M-triangle mesh, 1080p x 64 spp:
