@@ -1195,7 +1195,13 @@ int64_t orc_emit_photons(orc_scene* s, const rt_emit_params* e, int64_t first, i
         v3 nl = V(0, -1.0f, 0);
         float r1 = (float)(2 * PM_PI * edraw(&c)), r2 = edraw(&c), r2s = sqrtf(r2);
         v3 w = nl, u = vnorm(vcross(V(1.0f, 0, 0), w)), v = vcross(w, u);
-        v3 d = vadd(vadd(vmuls(vmuls(u, cosf(r1)), r2s), vmuls(vmuls(v, sinf(r1)), r2s)), vmuls(w, sqrtf(1 - r2)));
+        /* final.cpp:1071 calls std::cos(float) = glibc's cosf, which is not correctly rounded (0.56 ulp) and has FMA and
+         * non-FMA variants chosen at run time: a restatement through it is not reproducible between hosts, let alone on
+         * the device.  This emission is build-defined (counter-based draws), so it evaluates the cosine in double and
+         * rounds -- the correctly rounded float in all but ~1e-8 of the cases -- as kernels_emit.hip does.  (The pinning
+         * entry point orc_photon_trace_serial takes its emission rays from the reference itself.) */
+        const float cr1 = (float)cos((double)r1), sr1 = (float)sin((double)r1);
+        v3 d = vadd(vadd(vmuls(vmuls(u, cr1), r2s), vmuls(vmuls(v, sr1), r2s)), vmuls(w, sqrtf(1 - r2)));
         d = vnorm(d);
         v3 color = vload(e->power);
         if (e->which == RT_PMAP_GLOBAL) photon_trace(&c, pos, d, 0, e->start_nr, color);
