@@ -102,3 +102,40 @@ def test_emitted_map_through_build_and_knn(final_pair):
     ol.oracle().orc_pmap_knn(heap.ctypes.data, n, q.ctypes.data, 500, 100, 0.15, oi.ctypes.data, od.ctypes.data,
                              of.ctypes.data, orr.ctypes.data, C.byref(vis))
     assert np.array_equal(idx, oi) and np.array_equal(found, of) and d2.tobytes() == od.tobytes()
+
+
+def test_whole_map_pipeline_equals_the_oracles(final_pair):
+    """PhotonMappingImageSynthesis' two maps (final.cpp:1047-1129) made entirely on the GPU -- rt_photonmap_emit_dev until
+    the target is stored, rt_photonmap_build_dev (balance + ScalePhotonPower), the photons never on the host -- against
+    the same made entirely by the oracle (its emission, its balance, its scaling): the same heaps -- order, floats and
+    planes bit for bit -- and the same radiance estimates on them."""
+    import torch
+    from raytracer_amd import dist
+    sd, g, o = final_pair
+    targets, seed = (70_000, 3_000), 4242
+    maps = dist.build_photon_maps(g, torch, targets, seed)
+    for which, target in ((abi.RT_PMAP_GLOBAL, targets[0]), (abi.RT_PMAP_CAUSTIC, targets[1])):
+        e = host.final_emit_params(which, seed=seed)
+        parts, have, first, batch = [], 0, 0, 20_000
+        while have < target:                                   # `while (stored < max)`, any batching gives the same array
+            ph, _ = _oracle_emit(o, e, first, batch)
+            parts.append(ph); have += ph.size; first += batch
+        ref = np.zeros(target + 1, abi.photon_dtype); ref[1:] = np.concatenate(parts)[:target]
+        ol.oracle().orc_pmap_balance(ref.ctypes.data, target)
+        ref["power"][:target] *= np.float32(1.0) / np.float32(target)          # ScalePhotonPower(1/n, 0, n), photon.cpp:826-833
+        heap = maps[which]["heap"]
+        # every float field and the split planes bit for bit; the direction bytes are (int)(acosf / atan2f * 256/pi)
+        # (photon.cpp:870-876), device library against glibc: a value within an ulp of a whole number may land one step off
+        for f in ("position", "inDir", "power", "plane"):
+            assert heap[f][1:].tobytes() == ref[f][1:].tobytes(), (which, f)
+        for f in ("phi", "theta"):
+            d = np.abs(heap[f][1:].astype(int) - ref[f][1:].astype(int)); d = np.minimum(d, 256 - d)
+            assert d.max() <= 1 and (d > 0).sum() <= max(1, target // 20_000), (which, f, int((d > 0).sum()))
+    q = np.random.default_rng(3).uniform(-0.5, 0.5, (3000, 3)).astype(np.float32); q[:, 2] += 0.5; q[:1500, 1] = -0.5
+    nrm = np.zeros_like(q); nrm[:1500, 1] = 1.0; nrm[1500:, 2] = -1.0
+    got = g.photon_irradiance(abi.RT_PMAP_GLOBAL, q, nrm, 100, 0.3)
+    want = np.zeros((3000, 3), np.float32)
+    gh = np.ascontiguousarray(maps[0]["heap"])
+    ol.oracle().orc_pmap_irradiance(gh.ctypes.data, targets[0], q.ctypes.data, nrm.ctypes.data, 3000, 100, 0.3, want.ctypes.data)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-12) and (want > 0).any()
+
