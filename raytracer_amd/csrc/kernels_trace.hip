@@ -200,9 +200,10 @@ k_trace_any_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const in
 // the build's own hierarchy instead of the reference's tree (trace_device.h: traverse_bvh)
 extern "C" __global__ void __launch_bounds__(256)
 k_trace_closest_bvh(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                    int64_t n, float eps_f, rt_hit* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inb = i < n;
+                    int64_t n, float eps_f, rt_hit* __restrict__ out, const int32_t* __restrict__ order) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i0 < n;
+    const int64_t i = (inb && order) ? (int64_t)order[i0] : i0;      // `order` (rtk_ray_order): the wave's rays by direction octant
     const bool valid = inb && (active == nullptr || active[i] >= 0);
     Rayf r = {0, 0, 0, 0, 0, 1};
     if (valid) r = load_ray(rays, i);
@@ -219,9 +220,10 @@ k_trace_closest_bvh(DevSceneView sc, const rt_ray* __restrict__ rays, const int3
 
 extern "C" __global__ void __launch_bounds__(256)
 k_trace_any_bvh(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inb = i < n;
+                const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inb = i0 < n;
+    const int64_t i = (inb && order) ? (int64_t)order[i0] : i0;
     const bool valid = inb && (active == nullptr || active[i] >= 0);
     Rayf r = {0, 0, 0, 0, 0, 1};
     float tm = 0.f;
@@ -359,7 +361,7 @@ __device__ __forceinline__ unsigned ro_spread(unsigned v) {      // 10 bits -> e
 }
 struct RoBox { float lo[3], inv[3]; };
 extern "C" __global__ void __launch_bounds__(256)
-k_ray_keys(const rt_ray* __restrict__ rays, const int32_t* __restrict__ active, int64_t n, RoBox box,
+k_ray_keys(const rt_ray* __restrict__ rays, const int32_t* __restrict__ active, int64_t n, RoBox box, int octant_only,
            unsigned* __restrict__ keys, int32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -375,7 +377,8 @@ k_ray_keys(const rt_ray* __restrict__ rays, const int32_t* __restrict__ active, 
         }
         const unsigned oct = (r[3] < 0.f ? 1u : 0u) | (r[4] < 0.f ? 2u : 0u) | (r[5] < 0.f ? 4u : 0u);
         key = ((m >> 12) << 15) | (oct << 12) | (m & 0xfffu);
-    }
+        if (octant_only) key = oct;
+    } else if (octant_only) key = 8u;
     keys[i] = key; vals[i] = (int32_t)i;
 }
 
@@ -398,17 +401,19 @@ RoWork ro_carve(void* base, int64_t n) {
 
 size_t rtk_ray_order_workspace(int64_t n) { return n > 0 && n <= 0x7fffffff ? ro_carve(nullptr, n).total : 0; }
 
-// *order_out = n ray indices in traversal order (inside d_work), or NULL when n is too small to be worth a sort
+// *order_out = n ray indices in traversal order (inside d_work), or NULL when n is too small to be worth a sort.
+// octant_only: a stable partition by direction octant alone (one 4-bit pass; inactive slots last), for the wave-synchronous
+// closest-hit kernel (render.cpp)
 hipError_t rtk_ray_order(const rt_ray* d_rays, const int32_t* d_active, int64_t n, const float lo[3], const float hi[3],
-                         void* d_work, const int32_t** order_out, hipStream_t st) {
+                         void* d_work, const int32_t** order_out, hipStream_t st, int octant_only) {
     *order_out = nullptr;
     if (n < 4096 || n > 0x7fffffff || !d_work) return hipSuccess;
     const RoWork W = ro_carve(d_work, n);
     RoBox box;
     for (int a = 0; a < 3; ++a) { box.lo[a] = lo[a]; box.inv[a] = hi[a] > lo[a] ? 1.0f / (hi[a] - lo[a]) : 0.f; }
-    hipLaunchKernelGGL(k_ray_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rays, d_active, n, box, W.keys_in, W.vals_in);
+    hipLaunchKernelGGL(k_ray_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rays, d_active, n, box, octant_only, W.keys_in, W.vals_in);
     size_t temp = W.temp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)n, 0, 30, st);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)n, 0, octant_only ? 4 : 30, st);
     if (e != hipSuccess) return e;
     *order_out = W.vals_out;
     return hipGetLastError();
@@ -444,7 +449,7 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
                              float eps_f, int fast, rt_hit* d_out, hipStream_t st, const int32_t* d_order) {
     if (n <= 0) return hipSuccess;
     if (fast == 3) {
-        hipLaunchKernelGGL(k_trace_closest_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, d_out);
+        hipLaunchKernelGGL(k_trace_closest_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, d_out, d_order);
         return hipGetLastError();
     }
     if (fast == 2) {
@@ -466,7 +471,7 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
                          int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st, const int32_t* d_order) {
     if (n <= 0) return hipSuccess;
     if (fast == 3) {
-        hipLaunchKernelGGL(k_trace_any_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ);
+        hipLaunchKernelGGL(k_trace_any_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
         return hipGetLastError();
     }
     if (fast == 2) {

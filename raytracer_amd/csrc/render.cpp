@@ -203,9 +203,20 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         const bool sorted = pass_mode == 2 && s->ray_sort && s->view.nbvh > 0 && (s->fast == 1 || s->fast == 3);
         const int32_t* order_c = nullptr; const int32_t* order_a = nullptr;
         RTCHK(mark(st));
+        // wave-synchronous passes of secondary rays: a wave takes the one-octant walk (no min / max per box, nearest child
+        // first for every lane) only if all its rays point into one octant, and reflections off a curved surface do not.
+        // The closest-hit kernel therefore takes its rays in the order of a stable partition by direction octant (one 4-bit
+        // radix pass over (octant, index); within an octant the queue's pixel order stays) -- an order of work, results go to
+        // the rays' own slots.  1 M-triangle mesh, 1080p x 64 spp, pass 1 (49.5 M rays): 16.0 -> 11.8 ms with the partition
+        // inside; the any-hit kernel gains nothing from it (its rays aim at one light) and is left alone.  RT_OCT_PARTITION=0: off.
+        static const bool oct_partition = [] { const char* e = getenv("RT_OCT_PARTITION"); return e ? atoi(e) != 0 : true; }();
+        const bool by_octant = oct_partition && pass_mode == 3 && depth >= 1 && s->view.nbvh > 0;
         if (sorted) {
             void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
             HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st), "ray order");
+        } else if (by_octant) {
+            void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
+            HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st, 1), "ray order");
         }
         HIPCHK(rtk_trace_closest(view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c), "k_trace_closest");
         RTCHK(mark(st));
