@@ -402,18 +402,18 @@ RoWork ro_carve(void* base, int64_t n) {
 size_t rtk_ray_order_workspace(int64_t n) { return n > 0 && n <= 0x7fffffff ? ro_carve(nullptr, n).total : 0; }
 
 // *order_out = n ray indices in traversal order (inside d_work), or NULL when n is too small to be worth a sort.
-// octant_only: a stable partition by direction octant alone (one 4-bit pass; inactive slots last), for the wave-synchronous
-// closest-hit kernel (render.cpp)
+// what = RT_ORDER_OCTANT: a stable partition by direction octant alone (one 4-bit pass; inactive slots last), RT_ORDER_CELL:
+// by the 32^3 cell of the origin alone (the key's top 15 bits) -- for the wave-synchronous kernels (render.cpp)
 hipError_t rtk_ray_order(const rt_ray* d_rays, const int32_t* d_active, int64_t n, const float lo[3], const float hi[3],
-                         void* d_work, const int32_t** order_out, hipStream_t st, int octant_only) {
+                         void* d_work, const int32_t** order_out, hipStream_t st, int what) {
     *order_out = nullptr;
     if (n < 4096 || n > 0x7fffffff || !d_work) return hipSuccess;
     const RoWork W = ro_carve(d_work, n);
     RoBox box;
     for (int a = 0; a < 3; ++a) { box.lo[a] = lo[a]; box.inv[a] = hi[a] > lo[a] ? 1.0f / (hi[a] - lo[a]) : 0.f; }
-    hipLaunchKernelGGL(k_ray_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rays, d_active, n, box, octant_only, W.keys_in, W.vals_in);
+    hipLaunchKernelGGL(k_ray_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rays, d_active, n, box, what == RT_ORDER_OCTANT ? 1 : 0, W.keys_in, W.vals_in);
     size_t temp = W.temp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)n, 0, octant_only ? 4 : 30, st);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(W.temp, temp, W.keys_in, W.keys_out, W.vals_in, W.vals_out, (int)n, what == RT_ORDER_CELL ? 15 : 0, what == RT_ORDER_OCTANT ? 4 : 30, st);
     if (e != hipSuccess) return e;
     *order_out = W.vals_out;
     return hipGetLastError();

@@ -208,7 +208,11 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         // The closest-hit kernel therefore takes its rays in the order of a stable partition by direction octant (one 4-bit
         // radix pass over (octant, index); within an octant the queue's pixel order stays) -- an order of work, results go to
         // the rays' own slots.  1 M-triangle mesh, 1080p x 64 spp, pass 1 (49.5 M rays): 16.0 -> 11.8 ms with the partition
-        // inside; the any-hit kernel gains nothing from it (its rays aim at one light) and is left alone.  RT_OCT_PARTITION=0: off.
+        // inside.  The shadow rays of those hits all aim at the lights, so their octants say nothing, but their origins -- the
+        // hit points of reflections that have spread over the scene -- do: they are ordered by the 32^3 cell of the origin
+        // (two radix passes over the key's 15 cell bits): any-hit of pass 1 11.7 -> 8.9 ms, frame 90.5 -> 86.8 ms; cell +
+        // octant or the full 30-bit key give the same (87.7 / 87.3), the cell order for the closest-hit rays instead of the
+        // octants is slower (92.5), and either order for the per-lane passes is slower, again (90.4 - 97.7).  RT_OCT_PARTITION=0: off.
         static const bool oct_partition = [] { const char* e = getenv("RT_OCT_PARTITION"); return e ? atoi(e) != 0 : true; }();
         const bool by_octant = oct_partition && pass_mode == 3 && depth >= 1 && s->view.nbvh > 0;
         if (sorted) {
@@ -216,7 +220,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st), "ray order");
         } else if (by_octant) {
             void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
-            HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st, 1), "ray order");
+            HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st, RT_ORDER_OCTANT), "ray order");
         }
         HIPCHK(rtk_trace_closest(view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c), "k_trace_closest");
         RTCHK(mark(st));
@@ -230,9 +234,10 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         }
         RTCHK(mark(sb));
         if (L > 0) {
-            if (sorted) {
+            if (sorted || by_octant) {      // wave-synchronous shadow rays of secondary hits: by the cell of their origin (see above)
                 void* ow; RTCHK(s->scratch(S_ORDER_A, rtk_ray_order_workspace(n * L), &ow));
-                HIPCHK(rtk_ray_order((const rt_ray*)srays, (const int32_t*)sact, n * L, s->bvh_lo, s->bvh_hi, ow, &order_a, sb), "ray order");
+                HIPCHK(rtk_ray_order((const rt_ray*)srays, (const int32_t*)sact, n * L, s->bvh_lo, s->bvh_hi, ow, &order_a, sb,
+                                     sorted ? RT_ORDER_FULL : RT_ORDER_CELL), "ray order");
             }
             HIPCHK(rtk_trace_any(view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, sb, order_a), "k_trace_any");
         }

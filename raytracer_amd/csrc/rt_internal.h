@@ -214,8 +214,13 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
                          int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st, const int32_t* d_order = nullptr);
 size_t rtk_ray_order_workspace(int64_t n);
+// what rtk_ray_order sorts by: the whole key (cell of the origin, direction octant, finer Morton bits), the octant alone
+// (a stable partition), or the cell alone
+#define RT_ORDER_FULL 0
+#define RT_ORDER_OCTANT 1
+#define RT_ORDER_CELL 3
 hipError_t rtk_ray_order(const rt_ray* d_rays, const int32_t* d_active, int64_t n, const float lo[3], const float hi[3],
-                         void* d_work, const int32_t** order_out, hipStream_t st, int octant_only = 0);
+                         void* d_work, const int32_t** order_out, hipStream_t st, int what = RT_ORDER_FULL);
 hipError_t rtk_trace_work(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
                           int64_t n, float eps_f, int fast, int any, unsigned long long* d_out4, hipStream_t st);
 hipError_t rtk_generate_linear(const rt_camera& cam, int64_t first, int64_t n, float ox, float oy, rt_ray* d_rays,
