@@ -183,6 +183,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     DevSceneView view = s->view;
     if (overlap) view.lane_waves = 3072;                 // two per-lane kernels side by side (kernels_trace.hip: lanes_grid)
     hipEvent_t b_prev = nullptr, b_last = nullptr;      // the shadow half of the previous / the latest pass is done
+    hipEvent_t order_done = nullptr;                    // the second stream has ordered its shadow rays (rtk_ray_order)
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
         const int pass_mode = ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast;   // RT_OPT_LANE_DEPTH
         ++passes; pass_n.push_back(n); pass_lane.push_back(pass_mode == 2 ? 1 : 0);
@@ -222,6 +223,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
             HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st, RT_ORDER_OCTANT), "ray order");
         }
+        if (order_done) { HIPCHK(hipStreamWaitEvent(st, order_done, 0), "hipStreamWaitEvent"); order_done = nullptr; }
         HIPCHK(rtk_trace_closest(view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c), "k_trace_closest");
         RTCHK(mark(st));
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
@@ -238,6 +240,11 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
                 void* ow; RTCHK(s->scratch(S_ORDER_A, rtk_ray_order_workspace(n * L), &ow));
                 HIPCHK(rtk_ray_order((const rt_ray*)srays, (const int32_t*)sact, n * L, s->bvh_lo, s->bvh_hi, ow, &order_a, sb,
                                      sorted ? RT_ORDER_FULL : RT_ORDER_CELL), "ray order");
+                if (overlap && order_a) {       // the next pass's traversal starts after these radix passes: beside a per-lane
+                    hipError_t err;             // kernel's scattered reads they get a twentieth of their bandwidth (7 ms for 1 ms)
+                    order_done = bag.mark(sb, &err);
+                    if (!order_done) return rt_hipfail(err, "event");
+                }
             }
             HIPCHK(rtk_trace_any(view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, sb, order_a), "k_trace_any");
         }
