@@ -15,9 +15,9 @@ namespace {
 enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
     S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE, S_ORDER_C, S_ORDER_A,
-    S_HITS1, S_SRAYS1, S_SACTIVE1
+    S_HITS1, S_SRAYS1, S_SACTIVE1, S_HITS2, S_SRAYS2, S_SACTIVE2, S_QC_RAYS, S_QC_PIX, S_QC_W, S_QC_NR, S_QC_CODE
 };
-static_assert(S_SACTIVE1 < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_QC_CODE < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -182,18 +182,27 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     }
     DevSceneView view = s->view;
     if (overlap) view.lane_waves = 3072;                 // two per-lane kernels side by side (kernels_trace.hip: lanes_grid)
-    hipEvent_t b_prev = nullptr, b_last = nullptr;      // the shadow half of the previous / the latest pass is done
+    // With two streams the per-pass buffers rotate through THREE sets (hits, shadow rays, ray queues): the closest-hit stream
+    // may then run a whole pass ahead of the shadow stream -- with two sets it waited for the shadow half of pass d - 1
+    // before it could write pass d + 1's queue (2.3 ms of the 85 ms frame, profiles/r02_timeline_drt_1m.txt).
+    const int nsets = overlap ? 3 : 2;
+    std::vector<hipEvent_t> b_done;                     // b_done[d]: the shadow half of pass d is done
+    hipEvent_t b_last = nullptr;
+    static const int HITS_SLOT[3] = {S_HITS, S_HITS1, S_HITS2}, SRAYS_SLOT[3] = {S_SRAYS, S_SRAYS1, S_SRAYS2},
+                     SACT_SLOT[3] = {S_SACTIVE, S_SACTIVE1, S_SACTIVE2};
+    static const int Q_RAYS[3] = {S_QA_RAYS, S_QB_RAYS, S_QC_RAYS}, Q_PIX[3] = {S_QA_PIX, S_QB_PIX, S_QC_PIX}, Q_W[3] = {S_QA_W, S_QB_W, S_QC_W},
+                     Q_NR[3] = {S_QA_NR, S_QB_NR, S_QC_NR}, Q_CODE[3] = {S_QA_CODE, S_QB_CODE, S_QC_CODE};
     hipEvent_t order_done = nullptr;                    // the second stream has ordered its shadow rays (rtk_ray_order)
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
         const int pass_mode = ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast;   // RT_OPT_LANE_DEPTH
         ++passes; pass_n.push_back(n); pass_lane.push_back(pass_mode == 2 ? 1 : 0);
         const bool spawn = !p->primary_only && depth < p->max_depth;
-        const bool odd = overlap && (depth & 1);
+        const int set = overlap ? depth % 3 : 0;
         void *hits, *srays, *sact, *occ, *contrib, *flags = nullptr, *bsums = nullptr, *pairs;
         RTCHK(s->scratch(S_PAIRS, (size_t)((n + 255) / 256) * 8 + 16, &pairs));
-        RTCHK(s->scratch(odd ? S_HITS1 : S_HITS, (size_t)n * sizeof(rt_hit), &hits));
-        RTCHK(s->scratch(odd ? S_SRAYS1 : S_SRAYS, (size_t)n * L * sizeof(rt_ray), &srays));
-        RTCHK(s->scratch(odd ? S_SACTIVE1 : S_SACTIVE, (size_t)n * L * 4, &sact));
+        RTCHK(s->scratch(HITS_SLOT[set], (size_t)n * sizeof(rt_hit), &hits));
+        RTCHK(s->scratch(SRAYS_SLOT[set], (size_t)n * L * sizeof(rt_ray), &srays));
+        RTCHK(s->scratch(SACT_SLOT[set], (size_t)n * L * 4, &sact));
         RTCHK(s->scratch(S_OCC, (size_t)n * L, &occ));
         RTCHK(s->scratch(S_CONTRIB, (size_t)n * 12, &contrib));
         if (spawn) {
@@ -262,27 +271,28 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         if (overlap) {
             hipError_t err; b_last = bag.mark(sb, &err);
             if (!b_last) return rt_hipfail(err, "event");
+            b_done.push_back(b_last);
         }
         if (!spawn) break;
         // children -> the other queue, which the shadow half of the previous pass may still be reading
-        if (b_prev) HIPCHK(hipStreamWaitEvent(st, b_prev, 0), "hipStreamWaitEvent");
-        b_prev = b_last;
-        const bool toA = (depth % 2) == 0;
+        // (pass depth + 1 takes set (depth + 1) % 3, last used by pass depth - 2)
+        if (overlap && depth >= 2) HIPCHK(hipStreamWaitEvent(st, b_done[(size_t)depth - 2], 0), "hipStreamWaitEvent");
+        const int qo = (depth + 1) % nsets;               // the queue the children go to
         void *orays, *opix, *ow, *onr;
-        RTCHK(s->scratch(toA ? S_QA_RAYS : S_QB_RAYS, (size_t)n * 2 * sizeof(rt_ray), &orays));
-        RTCHK(s->scratch(toA ? S_QA_PIX : S_QB_PIX, (size_t)n * 2 * 4, &opix));
-        RTCHK(s->scratch(toA ? S_QA_W : S_QB_W, (size_t)n * 2 * 4, &ow));
-        RTCHK(s->scratch(toA ? S_QA_NR : S_QB_NR, (size_t)n * 2 * 4, &onr));
+        RTCHK(s->scratch(Q_RAYS[qo], (size_t)n * 2 * sizeof(rt_ray), &orays));
+        RTCHK(s->scratch(Q_PIX[qo], (size_t)n * 2 * 4, &opix));
+        RTCHK(s->scratch(Q_W[qo], (size_t)n * 2 * 4, &ow));
+        RTCHK(s->scratch(Q_NR[qo], (size_t)n * 2 * 4, &onr));
         const float* nr_in = q_nr;
         if (!nr_in && p->start_nr != 1.0f) {
             // first pass with a start index other than 1: materialise it (k_spawn treats NULL as 1.0)
-            void* tmp; RTCHK(s->scratch(toA ? S_QB_NR : S_QA_NR, (size_t)n * 4, &tmp));
+            void* tmp; RTCHK(s->scratch(Q_NR[(qo + 1) % nsets], (size_t)n * 4, &tmp));
             int nr_bits; memcpy(&nr_bits, &p->start_nr, 4);
             HIPCHK(hipMemsetD32Async((hipDeviceptr_t)tmp, nr_bits, (size_t)n, st), "fill nr");      // on the device: no pageable host copy
             nr_in = (const float*)tmp;
         }
         void* ocode = nullptr;
-        if (drt) RTCHK(s->scratch(toA ? S_QA_CODE : S_QB_CODE, (size_t)n * 2 * 4, &ocode));
+        if (drt) RTCHK(s->scratch(Q_CODE[qo], (size_t)n * 2 * 4, &ocode));
         HIPCHK(rtk_compact_children(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, nr_in, (const uint8_t*)flags, 2 * n,
                                     (uint32_t*)bsums, d_total, (rt_ray*)orays, (int32_t*)opix, (float*)ow, (float*)onr,
                                     d_ctr, q_code, (uint32_t*)ocode, p->seed, p->glossy, st), "compact children");

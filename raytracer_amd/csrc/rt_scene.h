@@ -3,7 +3,7 @@
 #include "rt_internal.h"
 #include <hip/hip_runtime_api.h>
 
-#define RT_NSCRATCH 40
+#define RT_NSCRATCH 48
 
 struct DeviceGuard {
     int prev, cur = -1; bool ok;
