@@ -170,10 +170,10 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const float* q_nr = nullptr;         // NULL = start_nr ... handled below
     int64_t n = n0;
     // The shadow half of a pass (any hit -> lights -> accumulate) does not feed the next pass: the children come from the
-    // closest hits alone.  It runs on the scene's second stream, beside the next pass's closest-hit traversal -- the deep
-    // passes of an incoherent frame are a few long walks each and leave most of the chip idle.  The hits and
-    // the shadow rays alternate between two buffers; a queue is rewritten only after the shadow half that reads it is done.
-    // Accumulation stays in pass order on that one stream, so the frame's bytes do not change.
+    // closest hits alone.  It runs on the scene's second stream, beside the next pass's closest-hit traversal -- in the deep
+    // passes of an incoherent frame two per-lane kernels side by side take the time of one.  A buffer set is
+    // rewritten only after the shadow half that reads it is done (events; below).  Accumulation stays in pass order on that
+    // one stream, so the frame's bytes do not change.
     const bool overlap = s->overlap_shadow && L > 0 && !d_work && !s->ray_sort && !p->primary_only && p->max_depth > 0;
     hipStream_t sb = st;
     if (overlap) {
