@@ -202,23 +202,23 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
         return d;
     };
     // visit(d2, idx, packed, own, on): one photon per lane; packed carries RT_PH_UNREACHABLE, and theta / phi when `own`
+    // The next record is chosen with the bound as it is BEFORE this node's photons are visited and fetched at once, so its
+    // latency runs beside the list insertions of the visits.  A bound that the visits would have tightened can only let a
+    // lane enter a sub-heap it would have skipped: more photons seen, the same k + 1 smallest kept.
     auto lane_walk = [&](bool start, auto&& bound, auto&& visit, unsigned& steps) {
         unsigned i = start ? 1u : 0u, pending = 0u;
+        // (a lane that is done reads record 0, which exists and is all zeros: no masked load, no registers to clear)
+        const float4* __restrict__ np = nodes64 + 4 * (size_t)i;
+        float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
         while (__ballot(i != 0u) != 0ull) {
             ++steps;
             const bool on = i != 0u;
-            // (a lane that is done reads record 0, which exists and is all zeros: no masked load, no registers to clear)
-            const float4* __restrict__ np = nodes64 + 4 * (size_t)i;
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             const unsigned pk = (unsigned)__float_as_int(q0.w);
-            visit(w_dist2(q0, qx, qy, qz), i, pk, true, on);
+            const float d_own = w_dist2(q0, qx, qy, qz);
             const unsigned c0 = 2u * i;
             const bool has_l = on && c0 <= un, has_r = on && c0 + 1u <= un;
             const float dl = boxdist6(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y), dr = boxdist6(q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
             const bool leaf_l = has_l && c0 > nb, leaf_r = has_r && c0 + 1u > nb;
-            if (dbg) d_lanes += (unsigned)(__popcll(__ballot(on)) + __popcll(__ballot(leaf_l)) + __popcll(__ballot(leaf_r)));   // photons examined
-            if (__ballot(leaf_l) != 0ull) visit(dl, c0, (pk & 8u) ? RT_PH_UNREACHABLE : 0u, false, leaf_l);
-            if (__ballot(leaf_r) != 0ull) visit(dr, c0 + 1u, (pk & 16u) ? RT_PH_UNREACHABLE : 0u, false, leaf_r);
             unsigned next = 0u;
             if (on) {
                 const float bd = bound();
@@ -234,10 +234,16 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
                 while (next == 0u && pending != 0u) {                      // the deepest deferred sibling the lane still wants
                     const int d = 31 - __builtin_clz(pending);
                     pending &= ~(1u << d);
-                    if (lane_stack[d * 64 + lane] <= bound()) next = (i >> (di - d)) ^ 1u;
+                    if (lane_stack[d * 64 + lane] <= bd) next = (i >> (di - d)) ^ 1u;
                 }
             }
-            i = next;
+            const float4* __restrict__ nn = nodes64 + 4 * (size_t)next;
+            const float4 n0 = nn[0], n1 = nn[1], n2 = nn[2], n3 = nn[3];
+            visit(d_own, i, pk, true, on);
+            if (dbg) d_lanes += (unsigned)(__popcll(__ballot(on)) + __popcll(__ballot(leaf_l)) + __popcll(__ballot(leaf_r)));   // photons examined
+            if (__ballot(leaf_l) != 0ull) visit(dl, c0, (pk & 8u) ? RT_PH_UNREACHABLE : 0u, false, leaf_l);
+            if (__ballot(leaf_r) != 0ull) visit(dr, c0 + 1u, (pk & 16u) ? RT_PH_UNREACHABLE : 0u, false, leaf_r);
+            i = next; q0 = n0; q1 = n1; q2 = n2; q3 = n3;
         }
     };
 
