@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X hot path on BASELINE.json's configuration 2:
-the bundled monkey scene at 3840x2160, primary + shadow rays only (materials overridden to
-reflect = refract = 0 as SURVEY 8d-2 says), traced by librt_hip.so through the C ABI.
+"""bench.py -- throughput of the MI355X hot path on BASELINE.json's configuration 3 (`configs[2]`, the configuration
+the metric's "1/2/4/8 GPUs" is quoted on): distributed ray tracing at 64 spp (jittered pixel samples, thin lens, ball
+light = soft shadows, glossy reflection, recursion depth <= 10) on the synthetic 1 M-triangle scene at 1920x1080, traced
+by librt_hip.so through the C ABI.  Every ray type is counted (primary + shadow + reflection + refraction).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one frame of the workload.  Everything the timed region reads (scene, KD-trees)
-is resident in HBM before it starts; rays are generated on the GPU.  N > 1: the frame grows
-with N (weak scaling: 3840x2160 pixels per GPU), 64x64 tiles are dealt round-robin to the
-ranks (no collective in the tracing path) and every step ends with the RCCL gather of the
-ranks' tiles to rank 0, as north_star prescribes.  Rank 0 prints ONE JSON line.
+A step = one frame of the workload.  Everything the timed region reads (scene, KD-trees, the build's hierarchy) is
+resident in HBM before it starts; rays are generated on the GPU.  N > 1: the frame grows with N (weak scaling:
+1920x1080 pixels x 64 spp per GPU), 64x64 tiles are dealt round-robin to the ranks (no collective in the tracing path)
+and every step ends with the RCCL gather of the ranks' tiles to rank 0, as north_star prescribes; the same frame at a
+FIXED size over N GPUs (strong scaling) is the line `secondary.drt_1m_strong`.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline      the dominant kernel against the limiter its counters support: `bound` is "hbm" when HBM
                 traffic is the largest of the three busy fractions, else "valu_issue" / "scalar_issue"; achieved / peak /
                 frac belong to that bound and frac <= 1 by construction.  Beside them: the SURVEY 8d algorithmic bytes
-                (per lane), the bytes the waves actually fetch (a record once per wave), the PMC HBM traffic.
-  cpu_baseline  the reference binary (oracle/_ref/hw4_ref) on a bounded sample of the same workload, 1 core
-  secondary     mesh_1m, drt_1m (BASELINE configuration 3), knn, photon_frame (configuration 4), each with its own
-                roofline, cpu_baseline and a parity sample checked against the oracle inside this run.
+                (per lane), the bytes the waves actually fetch (a record once per wave), the PMC HBM traffic, and
+                `counters_commit` / `counters_stale` (the commit the counters were collected at; stale = the kernel
+                sources have changed since).
+  cpu_baseline  the CPU leg on a bounded sample of the same workload, cores stated.  For the headline it is the oracle
+                port (`kind: "port"`): the reference has no distributed-ray-tracing samplers, so its binary cannot run
+                this workload; the lines whose workload the reference CAN run (monkey_4k, mesh_1m, knn, photon_frame)
+                time the reference itself (`kind: "reference"`).
+  secondary     monkey_4k (BASELINE configs[1]), mesh_1m, knn, photon_frame, photon_frame_full (configs[3] at its stated
+                size), stress_mesh_10m, stress_knn_200m (one GPU's share of configs[4]), each with its own roofline,
+                cpu_baseline and a parity sample checked against the oracle inside this run.
+Exit status: 0 = every line ran and its parity sample agreed; 3 = an N > 1 run stalled in a collective (the watchdog
+printed what there was); 4 = a secondary line failed or a parity sample disagreed (the JSON line is printed first).
 """
 import argparse
 import ctypes as C
@@ -41,10 +50,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_GINST = 1024 * 2.4 / 2.0          # wave-instructions / ns  -> 1228.8 G wave-instructions / s
 SCALAR_PEAK_GINST = 256 * 2.4               # SALU + SMEM + branch instructions, one per cycle and CU -> 614.4 G / s
-BASE_RES = (3840, 2160)
+BASE_RES = (3840, 2160)                     # the 4K frames of monkey_4k / mesh_1m / stress_mesh_10m
+HEAD_RES, HEAD_SPP = (1920, 1080), 64       # the headline: BASELINE configs[2]
 TILE = 64
 WEAK_FACTORS = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
-PROFILE_TAG = "r02"
+PROFILE_TAGS = ("r03", "r02")               # profiles/<tag>_counters.json, newest first
 
 
 def log(*a):
@@ -62,8 +72,9 @@ def bench_scene():
 
 
 def frame_for(n):
+    """weak scaling of the headline: 1920x1080 pixels (x 64 spp) per GPU"""
     fx, fy = WEAK_FACTORS.get(n, (n, 1))
-    return BASE_RES[0] * fx, BASE_RES[1] * fy
+    return HEAD_RES[0] * fx, HEAD_RES[1] * fy
 
 
 def rank_pixel_index(resx, resy, rank, nranks, tile=TILE):
@@ -83,28 +94,53 @@ def rank_pixel_index(resx, resy, rank, nranks, tile=TILE):
 # roofline
 
 _COUNTERS = None
+KERNEL_SOURCE_GLOBS = ("raytracer_amd/csrc/*.hip", "raytracer_amd/csrc/*.h", "raytracer_amd/csrc/*.cpp", "raytracer_amd/csrc/Makefile")
+
+
+def kernel_source_sha():
+    """sha256 over the library's sources (sorted by name): what the counters in profiles/ are stamped with
+    (tools/prof_counters.py) and compared against, so that counters older than the kernels are flagged"""
+    import glob
+    h = hashlib.sha256()
+    for g in KERNEL_SOURCE_GLOBS:
+        for f in sorted(glob.glob(os.path.join(ROOT, g))):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def counters(workload, kernel):
     """per-launch counters of `kernel` in `workload` from the committed rocprofv3 passes (tools/prof_all.sh ->
     tools/prof_counters.py -> profiles/<tag>_counters.json): HBM bytes (PMC, gfx950-corrected), L2 hit rate, SQ instruction
-    counts.  They are properties of the kernel on this workload, not of a run; the time is measured live."""
+    counts.  They are properties of the kernel on this workload, not of a run; the time is measured live.  Returns
+    (counters or None, provenance): provenance names the file, the commit and source hash the workload's counters were
+    collected at, and whether the sources have changed since (`stale`)."""
     global _COUNTERS
     if _COUNTERS is None:
-        _COUNTERS = {}
-        for name in (f"{PROFILE_TAG}_counters.json", "traffic_r01.json"):
-            p = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(p):
-                try:
-                    _COUNTERS = json.load(open(p)); _COUNTERS["_source"] = "profiles/" + name
-                    break
-                except Exception:
-                    pass
-    w = _COUNTERS.get(workload, {})
-    for k, v in w.items():
+        _COUNTERS = {"_files": []}
+        live = kernel_source_sha()
+        for tag in PROFILE_TAGS:             # newest first: a workload's counters come from the newest file that has them
+            p = os.path.join(ROOT, "profiles", f"{tag}_counters.json")
+            if not os.path.exists(p):
+                continue
+            try:
+                j = json.load(open(p))
+            except Exception:
+                continue
+            meta = j.get("_meta", {})
+            for w, ks in j.items():
+                if w.startswith("_") or w in _COUNTERS:
+                    continue
+                m = meta.get(w, {})
+                _COUNTERS[w] = dict(kernels=ks, prov=dict(source=f"profiles/{tag}_counters.json", commit=m.get("commit"),
+                                                          kernel_source_sha=m.get("kernel_source_sha"),
+                                                          stale=(m.get("kernel_source_sha") != live)))
+    w = _COUNTERS.get(workload)
+    if not w:
+        return None, dict(source=None, commit=None, kernel_source_sha=None, stale=None)
+    for k, v in w["kernels"].items():
         if k == kernel or k.startswith(kernel + "<"):
-            return v, _COUNTERS.get("_source")
-    return None, _COUNTERS.get("_source")
+            return v, w["prov"]
+    return None, w["prov"]
 
 
 def make_roofline(workload, kernel, avg_ms, units_per_launch, alg_bytes, wave_bytes=None, **detail):
@@ -143,7 +179,8 @@ def make_roofline(workload, kernel, avg_ms, units_per_launch, alg_bytes, wave_by
                l2_hit_rate=c.get("l2_hit_rate") if c else None,
                wait_inst_fraction=(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]) if c and c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_INST_ANY") else None,
                wait_memory_fraction=(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c and c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") else None,
-               counters_source=src, **detail)
+               counters_source=src.get("source"), counters_commit=src.get("commit"),
+               counters_kernel_source_sha=src.get("kernel_source_sha"), counters_stale=src.get("stale"), **detail)
     if note:
         out["note"] = note
     return out
@@ -348,6 +385,22 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
         found_mean = float(fnd.mean())
         cpu = dict(value=ns / cpu_s, unit="lookups/s", cores=1, kind="port", sample=f"{ns} of the same queries, oracle LocatePhoton",
                    seconds=cpu_s)
+        ref_rgb = None
+        if ol.have_ref():
+            # the reference itself (oracle/_ref/libref_photon.so: the unmodified PhotonMap of photon.cpp) on the same heap:
+            # CalcIrradiance = LocatePhoton + the sum, photon.cpp:342-443, for the same queries, one core
+            R = ol.ref_photon()
+            R.refp_create(n_photons)
+            R.refp_load(a.ctypes.data, n_photons)
+            ref_rgb = np.zeros((ns, 3), np.float32)
+            t0 = time.perf_counter()
+            R.refp_irradiance(qs.ctypes.data, qn.ctypes.data, ns, radius, k, ref_rgb.ctypes.data)
+            ref_s = time.perf_counter() - t0
+            R.refp_create(1)                       # gives the reference's copy of the map back
+            cpu = dict(value=ns / ref_s, unit="lookups/s", cores=1, kind="reference",
+                       sample=f"{ns} of the same queries on the same heap, the reference's own CalcIrradiance "
+                              "(LocatePhoton + sum, oracle/_ref/libref_photon.so)", seconds=ref_s,
+                       port_lookups_per_s=ns / cpu_s)
         # parity sample: the oracle's CalcIrradiance for those queries against what the timed kernel wrote for them, and the
         # strict kernel's index lists against the oracle's
         orgb = np.zeros((ns, 3), np.float32)
@@ -357,7 +410,11 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
         parity = dict(queries=ns, irradiance_within_1e5_rel=bool(np.allclose(grgb, orgb, rtol=1e-5, atol=1e-12)),
                       max_rel_err=float((np.abs(grgb - orgb) / np.maximum(np.abs(orgb), 1e-30)).max()),
                       index_lists_bit_exact=bool(np.array_equal(gi, idx[:500]) and np.array_equal(gf, fnd[:500]) and gd.tobytes() == d2[:500].tobytes()))
-        parity["parity_sample_ok"] = parity["irradiance_within_1e5_rel"] and parity["index_lists_bit_exact"]
+        if ref_rgb is not None:               # and against the reference's own answers
+            parity["irradiance_within_1e5_rel_of_reference"] = bool(np.allclose(grgb, ref_rgb, rtol=1e-5, atol=1e-12))
+            parity["oracle_equals_reference_bits"] = bool(orgb.tobytes() == ref_rgb.tobytes())
+        parity["parity_sample_ok"] = bool(parity["irradiance_within_1e5_rel"] and parity["index_lists_bit_exact"] and
+                                          parity.get("irradiance_within_1e5_rel_of_reference", True))
     if ks[6] > 0:          # the wave-shared kernels ran
         visits = float(ks[0] + ks[12]) / n_queries
         detail = dict(waves=int(ks[6]), phase1_fetches_per_lookup=float(ks[0]) / n_queries,
@@ -367,7 +424,7 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     else:
         visits, detail, kernel = (ref_visits or 0.0), dict(), "k_photon_knn"
     bytes_per = 24 + 16 * visits + 12 * found_mean + 12
-    rf = make_roofline("knn_10m" if n_photons == 10_000_000 else f"knn_{n_photons}", kernel, ms, n_queries, bytes_per * n_queries,
+    rf = make_roofline({10_000_000: "knn_10m", 200_000_000: "stress_knn_200m"}.get(n_photons, f"knn_{n_photons}"), kernel, ms, n_queries, bytes_per * n_queries,
                        visits_per_lookup=visits, bytes_per_lookup=bytes_per, reference_visits_per_lookup=ref_visits,
                        time_is="whole step (query sort + k_irr_main + strict redo), HIP events", **detail)
     return dict(metric="kNN radiance lookups/s", value=n_queries / (ms * 1e-3), unit="lookups/s",
@@ -441,24 +498,24 @@ def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500, tag="mesh_1m", c
 DRT_KW = dict(lens_radius=0.01, focal_distance=1.3, light_radius=0.5, glossy=0.05, seed=3)
 
 
-def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
-    """BASELINE configuration 3: distributed ray tracing at 64 spp (jittered pixel samples, thin lens, ball light =
-    soft shadows, glossy reflection) on the synthetic 1 M-triangle scene.  The samplers are build-defined (the reference
-    has none); every ray type is counted."""
-    from raytracer_amd import abi, host, synth
+def drt_analysis(torch, gs, sd, cam, p, sp, with_cpu=True):
+    """BASELINE configuration 3's frame, instrumented (after the timed region): ray counts and the frame's own kernel time
+    from rt_stats; the per-kernel HIP-event times of the roofline from one more frame with every kernel on one stream; the
+    work counters from a frame with rt_params.count_work; and, with `with_cpu`, the CPU leg + parity sample: the oracle's
+    restatement of the same samplers on a small frame against the GPU on that frame.  The samplers are build-defined (the
+    reference has none), so this leg is `kind: "port"` by necessity."""
+    from raytracer_amd import abi, host
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    sd = synth.mesh_scene(nu, nv, reflect=0.3)
-    gs = host.Scene(sd, device=local_rank)
-    cam = host.camera_for(sd, res)
-    p = host.default_params("hw4", spp=spp, **DRT_KW)
+    res = (cam.resx, cam.resy)
     frame = torch.zeros(res[0] * res[1] * 3, dtype=torch.uint8, device="cuda")
     st = abi.rt_stats()
-    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(2):
         abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(p), frame.data_ptr(), None, C.byref(st), sp))
     rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
     frame_ms = st.kernel_ms
+    counts = dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract)
+    passes = st.passes
     # the per-kernel times of the roofline come from one more frame with every kernel on one stream: in the timed frame the
     # shadow half of a pass shares the chip with the next pass's closest-hit kernel, and two kernels side by side time each other
     abi.check(gs.L.rt_scene_set_option(gs.h, abi.RT_OPT_RENDER_OVERLAP, 0))
@@ -487,33 +544,98 @@ def drt_secondary(torch, local_rank, res=(1920, 1080), spp=64, nu=1000, nv=500):
                        time_is="HIP events around the kernel's launches in a frame with every kernel on one stream "
                                "(RT_OPT_RENDER_OVERLAP 0); `value` is the two-stream frame",
                        box_tests_per_ray=work[0] / max(1, krays), tri_records_per_ray=work[1] / max(1, krays),
-                       traversal_ms_by_kernel={k: v[0] for k, v in fam.items()})
-    # CPU baseline + parity sample: the oracle's restatement of the same samplers on a small frame, and the GPU on that frame
-    o = ol.OracleScene(sd)
-    cres, cspp = (128, 72), 8
-    pc = host.default_params("hw4", spp=cspp, **DRT_KW)
+                       traversal_ms_by_kernel={k: v[0] for k, v in fam.items()},
+                       traversal_launches_by_kernel={k: int(v[1]) for k, v in fam.items()},
+                       traversal_rays_by_kernel={k: int(v[2]) for k, v in fam.items()})
+    out = dict(rays=rays, frame_ms=frame_ms, counts=counts, passes=passes, trace_closest_ms=st.trace_closest_ms,
+               trace_any_ms=st.trace_any_ms, roofline=rf, cpu_baseline=None, parity=None)
+    if with_cpu:
+        o = ol.OracleScene(sd)
+        cres, cspp = (128, 72), 8
+        pc = host.default_params("hw4", spp=cspp, **DRT_KW)
+        t0 = time.perf_counter()
+        orgb, oids, _ = o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), pc)
+        cpu_s = time.perf_counter() - t0
+        crays = o.counters().rays_traced
+        o.close()
+        grgb, gids, _ = gs.render(host.camera_for(sd, cres), pc, want_ids=True)
+        d = np.abs(grgb.astype(int) - orgb.reshape(grgb.shape).astype(int)).max(-1)
+        out["parity"] = dict(frame=list(cres), spp=cspp, hit_ids_equal=bool(np.array_equal(gids, oids)),
+                             pixels_off_by_more_than_1lsb=int((d > 1).sum()),
+                             parity_sample_ok=bool(np.array_equal(gids, oids) and (d > 1).sum() <= 0.005 * cres[0] * cres[1]),
+                             note="parity unpinned: the samplers are build-defined, the checker is the oracle's restatement of them")
+        out["cpu_baseline"] = dict(value=crays / cpu_s / 1e6, unit="Mrays/s", cores=1, kind="port",
+                                   sample=f"the same scene and samplers at {cres[0]}x{cres[1]}, {cspp} spp, oracle port "
+                                          "(the reference has no such samplers, so its binary cannot run this workload)",
+                                   seconds=cpu_s, rays=int(crays))
+    return out
+
+
+def drt_workload(sd, res, spp):
+    return (f"BASELINE configs[2]: synthetic mesh, {sd.nprim} triangles, {res[0]}x{res[1]}, {spp} spp, lens 0.01 / focus 1.3, "
+            "light ball 0.5, glossy 0.05, reflect 0.3 (sphere) / 0.5 (floor), depth <= 10")
+
+
+def monkey_secondary(torch, local_rank, steps=20, warmup=5, cpu=None):
+    """BASELINE configs[1] (the headline of rounds 1-2): the bundled monkey scene at 3840x2160, primary + shadow rays only
+    (materials' reflect / refract set to 0); the frame's hit-id image against the reference's own 4K digest."""
+    from raytracer_amd import abi, host
+    sd = bench_scene()
+    gs = host.Scene(sd, device=local_rank)
+    resx, resy = BASE_RES
+    cam = host.camera_for(sd, BASE_RES)
+    params = host.default_params("hw4", primary_only=1)
+    frame = torch.zeros(resx * resy * 3, dtype=torch.uint8, device="cuda")
+    hit_ids = torch.zeros(resx * resy, dtype=torch.int32, device="cuda")
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = abi.rt_stats()
+    render = lambda ids, stats: abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), frame.data_ptr(),
+                                                             hit_ids.data_ptr() if ids else None, C.byref(st) if stats else None, sp))
+    for _ in range(warmup):
+        render(False, False)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    orgb, oids, _ = o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *cres), pc)
-    cpu_s = time.perf_counter() - t0
-    crays = o.counters().rays_traced
-    o.close()
-    grgb, gids, _ = gs.render(host.camera_for(sd, cres), pc, want_ids=True)
-    d = np.abs(grgb.astype(int) - orgb.reshape(grgb.shape).astype(int)).max(-1)
-    parity = dict(frame=list(cres), spp=cspp, hit_ids_equal=bool(np.array_equal(gids, oids)),
-                  pixels_off_by_more_than_1lsb=int((d > 1).sum()),
-                  parity_sample_ok=bool(np.array_equal(gids, oids) and (d > 1).sum() <= 0.005 * cres[0] * cres[1]),
-                  note="parity unpinned: the samplers are build-defined, the checker is the oracle's restatement of them")
+    for _ in range(steps):           # no rt_stats: the frames queue on the stream back to back
+        render(False, False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tot = dict(rays=0, closest_ms=0.0, launches=0, prim=0, shadow=0, any_launches=0)
+    nstat = max(1, min(steps, 20))
+    for _ in range(nstat):
+        render(True, True)
+        tot["rays"] += st.rays_primary + st.rays_shadow; tot["closest_ms"] += st.trace_closest_ms
+        tot["launches"] += st.trace_closest_launches; tot["prim"] += st.rays_primary; tot["shadow"] += st.rays_shadow
+        tot["any_launches"] += st.trace_any_launches
+    rays_per_step = tot["rays"] / nstat
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "monkey4k_hits_digest.npz"))
+        ids = hit_ids.cpu().numpy()
+        dig = hashlib.sha256(np.ascontiguousarray(ids.reshape(resy, resx).T.astype("<i4")).tobytes()).hexdigest()   # the reference's x-major order
+        want_dig = str(g["sha256_ids_xy"].item())
+        parity = dict(frame=[resx, resy], hit_id_sha256=dig, reference_sha256=want_dig, parity_sample_ok=bool(dig == want_dig))
+    except Exception as e:
+        parity = dict(error=f"{type(e).__name__}: {e}", parity_sample_ok=False)
+    stw = render_work(gs, cam, params, sp, torch)
+    launches = max(1, tot["launches"])
+    fused = tot["any_launches"] == 0 and tot["shadow"] > 0       # the whole frame is ONE kernel (k_primary_only)
+    alg_c, wave_c = traversal_bytes(stw.closest_work, stw.rays_primary)
+    alg_a, wave_a = traversal_bytes(stw.any_work, stw.rays_shadow, out_bytes=1)
+    kernel = "k_primary_only" if fused else "k_trace_closest_bvh"
+    rf = make_roofline(
+        "monkey_4k", kernel, tot["closest_ms"] / launches, (tot["prim"] + (tot["shadow"] if fused else 0)) / launches,
+        alg_c + (alg_a if fused else 0.0), wave_c + (wave_a if fused else 0.0),
+        box_tests_per_ray=stw.closest_work[0] / max(1, stw.rays_primary), tri_records_per_ray=stw.closest_work[1] / max(1, stw.rays_primary),
+        exact_tri_tests_per_ray=stw.closest_work[2] / max(1, stw.rays_primary),
+        shadow_box_tests_per_ray=stw.any_work[0] / max(1, stw.rays_shadow), shadow_tri_records_per_ray=stw.any_work[1] / max(1, stw.rays_shadow),
+        note=("one fused kernel traces the primary AND the shadow rays (generate, closest hit, any hit, shade, pixel). " if fused else "") +
+             "The scene (87 KB) lives in the scalar cache / L2: HBM sees the frame that is written and little else, so the "
+             "kernel is priced against instruction issue; see DESIGN.md 4.1d / 5")
     gs.close()
-    return dict(metric="Mrays/s (distributed ray tracing, all ray types)", value=rays / (frame_ms * 1e-3) / 1e6, unit="Mrays/s",
-                ms_per_frame=frame_ms, passes=st.passes,
-                config=dict(workload=f"synthetic mesh, {sd.nprim} triangles, {res[0]}x{res[1]}, {spp} spp, lens 0.01 / focus 1.3, "
-                                     "light ball 0.5, glossy 0.05, reflect 0.3 (sphere) / 0.5 (floor), depth <= 10"),
-                rays=dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract),
-                trace_closest_ms=st.trace_closest_ms, trace_any_ms=st.trace_any_ms, roofline=rf,
-                cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", cores=1, kind="port",
-                                  sample=f"the same scene and samplers at {cres[0]}x{cres[1]}, {cspp} spp, oracle port "
-                                         "(the reference has no such samplers)", seconds=cpu_s),
-                parity=parity)
+    return dict(metric="Mrays/s (KD-tree traversal, primary + shadow rays)", value=rays_per_step * steps / dt / 1e6, unit="Mrays/s",
+                ms_per_step=dt / steps * 1e3, steps=steps,
+                config=dict(workload="BASELINE configs[1]: bundled monkey scene (970 triangles, 138 KD nodes), "
+                                     f"{resx}x{resy}, primary + shadow rays only, reflect=refract=0", rays_per_step=rays_per_step),
+                roofline=rf, cpu_baseline=cpu, parity=parity)
 
 
 def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_000, res=(192, 192), tag="photon_frame"):
@@ -566,6 +688,40 @@ def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_
                   pixels_off_by_more_than_1lsb=int((d > 1).sum()),
                   parity_sample_ok=bool(np.array_equal(gids, np.asarray(oids).reshape(gids.shape)) and (d > 1).sum() <= 1))
     gs.close()
+    cpu_line = dict(value=crays / cpu_s / 1e6, unit="Mrays/s", lookups_per_s=c.knn_lookups / cpu_s, cores=1,
+                    kind="port", sample=f"the same frame at {cres[0]}x{cres[1]}, same photon maps, oracle port", seconds=cpu_s)
+    if ol.have_ref() and n_global <= 20_000_000:
+        # the reference itself (oracle/_ref/libref_final.so: the unmodified SimpleMeshRayTrace(pmap, cpmap, ...) of
+        # final.cpp:785-983 with TraceIrradiance / CalcIrradiance / IsInShadow below it) on the same scene and the same two
+        # heaps, the primary rays of an 8x8 frame, 1 tap; one core.  Its gather directions come from its own serial engine, so
+        # its rays are counted by the oracle port on that frame and its radiance is not a parity sample.
+        try:
+            R = ol.ref_final_build_scene(sd)
+            cs = np.array([0.2, -0.3, 0.45, 0.2], np.float32); R.reff_add_caustic_sphere(cs.ctypes.data)
+            R.reff_maps_create(n_global, n_caustic)
+            R.reff_map_load(0, maps[0]["heap"].ctypes.data, n_global); R.reff_map_load(1, maps[1]["heap"].ctypes.data, n_caustic)
+            rres = (8, 8)
+            rcam = ol.oracle_camera(sd.eye, sd.view, sd.fov, *rres)
+            xs, ys = np.meshgrid(np.arange(rres[0]), np.arange(rres[1]), indexing="ij")
+            rays = ol.oracle_primary_rays(rcam, xs.ravel(), ys.ravel())
+            o3 = np.ascontiguousarray(rays[:, :3]); d3 = np.ascontiguousarray(rays[:, 3:])
+            rrgb = np.zeros((rays.shape[0], 3), np.float32); ha = np.zeros(rays.shape[0], np.uint8)
+            t0 = time.perf_counter()
+            R.reff_eye_trace(o3.ctypes.data, d3.ctypes.data, 0, 2.4, rays.shape[0], rrgb.ctypes.data, ha.ctypes.data)
+            ref_s = time.perf_counter() - t0
+            R.reff_maps_create(1, 1)
+            o2 = ol.OracleScene(sd)
+            o2.render_photon(rcam, p, maps[0]["heap"], maps[1]["heap"])
+            c2 = o2.counters()
+            rrays = c2.rays_primary + c2.rays_shadow + c2.rays_reflect + c2.rays_refract + c2.rays_gather
+            o2.close()
+            cpu_line = dict(value=rrays / ref_s / 1e6, unit="Mrays/s", lookups_per_s=c2.knn_lookups / ref_s, cores=1, kind="reference",
+                            sample=f"the same scene and photon maps, the primary rays of an {rres[0]}x{rres[1]} frame (1 tap) through the "
+                                   "reference's own SimpleMeshRayTrace(pmap, cpmap) (oracle/_ref/libref_final.so); rays and lookups "
+                                   "counted by the oracle port on that frame", seconds=ref_s,
+                            port_mrays_per_s=crays / cpu_s / 1e6, port_lookups_per_s=c.knn_lookups / cpu_s)
+        except Exception as e:
+            log(f"reference leg of {tag} failed: {type(e).__name__}: {e}")
     return dict(metric="photon-mapping frame: Mrays/s and kNN radiance lookups/s", value=rays / (st.kernel_ms * 1e-3) / 1e6,
                 unit="Mrays/s", lookups_per_s=st.knn_lookups / (st.kernel_ms * 1e-3), ms_per_frame=st.kernel_ms,
                 config=dict(workload=f"bundled Final scene, {res[0]}x{res[1]}, 1 AA tap, 50 gather rays, 20x20 light samples, k=100",
@@ -573,10 +729,7 @@ def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_
                             emissions_caustic=maps[1]["emissions"], maps_emit_balance_upload_s=maps_s),
                 rays=dict(primary=st.rays_primary, shadow=st.rays_shadow, reflect=st.rays_reflect, refract=st.rays_refract,
                           gather=st.rays_gather), knn_lookups=st.knn_lookups, roofline=rf,
-                cpu_baseline=dict(value=crays / cpu_s / 1e6, unit="Mrays/s", lookups_per_s=c.knn_lookups / cpu_s, cores=1,
-                                  kind="port", sample=f"the same frame at {cres[0]}x{cres[1]}, same photon maps, oracle port",
-                                  seconds=cpu_s),
-                parity=parity)
+                cpu_baseline=cpu_line, parity=parity)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -615,16 +768,18 @@ class Coll:
                 a.copy_(b)
 
 
-def drt_strong(torch, coll, rank, n, local_rank, res=(1920, 1080), spp=64, steps=2):
+def drt_strong(torch, coll, rank, n, local_rank, res=(1920, 1080), spp=64, steps=2, gs=None, sd=None):
     """BASELINE configuration 3 over N GPUs, STRONG scaling: the fixed 1080p x 64 spp frame, 64x64 tiles round-robin, each
     rank's pixels written packed (rt_params.packed_output) and gathered to rank 0; time = slowest rank incl. the gather."""
     from raytracer_amd import abi, host, synth
     dev = torch.device("cuda", local_rank)
-    gs = cam = None
+    cam = None
     ok = True
+    own = gs is None                 # the headline's scene is this configuration's scene: reuse it
     try:
-        sd = synth.mesh_scene(1000, 500, reflect=0.3)
-        gs = host.Scene(sd, device=local_rank)
+        if own:
+            sd = synth.mesh_scene(1000, 500, reflect=0.3)
+            gs = host.Scene(sd, device=local_rank)
         cam = host.camera_for(sd, res)
         plist = [host.pixel_list(cam, host.default_params("hw4", tile_size=TILE, tile_rank=r, tile_nranks=n)) for r in range(n)]
         counts = [int(l.size) for l in plist]
@@ -671,7 +826,8 @@ def drt_strong(torch, coll, rank, n, local_rank, res=(1920, 1080), spp=64, steps
                    config=dict(workload=f"BASELINE configs[2]: 1 M-triangle mesh, {res[0]}x{res[1]}, {spp} spp, tiles {TILE}x{TILE} "
                                         f"round-robin over {n} GPUs, packed gather to rank 0",
                                assembled_frame_equals_one_gpu_frame=bool(torch.equal(final.view(-1), whole))))
-    gs.close()
+    if own:
+        gs.close()
     return out
 
 
@@ -732,14 +888,34 @@ class _HostDist:
 
 # ---------------------------------------------------------------------------------------------------------------------
 
+EXIT_STALLED, EXIT_LINE_FAILED = 3, 4
+
+
+def line_failed(line):
+    """a secondary line that raised, or whose parity sample disagreed"""
+    if not isinstance(line, dict):
+        return True
+    if "error" in line:
+        return True
+    par = line.get("parity")
+    if isinstance(par, dict) and par.get("parity_sample_ok") is False:
+        return True
+    cfg = line.get("config", {})
+    for k in ("assembled_frame_equals_one_gpu_frame", "heap_equals_one_rank_heap", "every_rank_answers_alike"):
+        if cfg.get(k) is False:
+            return True
+    return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-knn", action="store_true", help="skip the secondary lines (kNN, 1M-triangle mesh, photon frame)")
-    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: knn,mesh_1m,drt_1m,photon_frame (and, on request only: stress_mesh_10m,stress_knn_200m,photon_frame_full)")
+    ap.add_argument("--no-knn", action="store_true", help="skip the secondary lines")
+    ap.add_argument("--no-full-size", action="store_true", help="skip photon_frame_full, stress_mesh_10m, stress_knn_200m (quick runs)")
+    ap.add_argument("--only-secondary", type=str, default="", help="comma list of secondary lines to run: monkey_4k,knn,mesh_1m,photon_frame,photon_frame_full,stress_mesh_10m,stress_knn_200m (N > 1: knn,drt_1m_strong,emission_sharded)")
     ap.add_argument("--knn-photons", type=int, default=10_000_000)
     ap.add_argument("--knn-queries", type=int, default=1920 * 1080)
     ap.add_argument("--cpu-sample", type=str, default="960x540")
@@ -754,22 +930,24 @@ def main():
     dry = args.dry_run
     rehearse = n > 1 and args.backend == "gloo" and not dry
     only = [x for x in args.only_secondary.split(",") if x]
-    want = lambda name: (not args.no_knn) and ((name in only) if (only or name.startswith("stress_") or name.endswith("_full")) else True)
+    full_size = ("photon_frame_full", "stress_mesh_10m", "stress_knn_200m")
+    want = lambda name: (not args.no_knn) and ((name in only) if only else not (args.no_full_size and name in full_size))
 
     # ---- CPU legs that fork (reference binaries, process pool): before anything touches the GPU ----------------------
-    sd = bench_scene()
     cpu = {}
     if rank == 0 and n == 1 and not dry and not args.no_cpu_baseline:
         w, h = (int(x) for x in args.cpu_sample.split("x"))
         t0 = time.perf_counter()
-        try:
-            cpu["headline"] = cpu_baseline_monkey(sd, (w, h))
-        except Exception as e:
-            cpu["headline"] = {"error": f"{type(e).__name__}: {e}"}
-        try:
-            cpu["headline"]["all_cores"] = cpu_port_all_cores(sd, (w, h))
-        except Exception as e:      # a reported extra, never a reason to lose the line
-            cpu["headline"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
+        if want("monkey_4k"):
+            msd = bench_scene()
+            try:
+                cpu["monkey_4k"] = cpu_baseline_monkey(msd, (w, h))
+            except Exception as e:
+                cpu["monkey_4k"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                cpu["monkey_4k"]["all_cores"] = cpu_port_all_cores(msd, (w, h))
+            except Exception as e:      # a reported extra, never a reason to lose the line
+                cpu["monkey_4k"]["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
         if want("mesh_1m"):
             try:
                 cpu["mesh_1m"] = cpu_baseline_mesh()
@@ -792,21 +970,48 @@ def main():
         dist.init_process_group(backend="gloo" if (dry or rehearse) else "nccl")
     coll = Coll(dist, torch, "gloo" if (dry or rehearse) else "nccl") if n > 1 else None
 
+    # Every rank of an N > 1 run sits in collectives from here on; if one of them dies or stalls the others would wait for
+    # ever.  After RT_BENCH_WATCHDOG_S seconds (default 360) without the run finishing, every rank gives up: rank 0 prints the
+    # line as it stands, marked, and the process ends with a NON-ZERO status -- a stalled run must never read as a success.
+    out = None
+    watchdog = None
+    if n > 1:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line = dict(out) if out else {"metric": "Mrays/s (distributed ray tracing, all ray types)", "value": None, "n_gpus": n}
+                line["error"] = f"the N = {n} run did not finish within its time limit: a rank stalled in a collective"
+                print(json.dumps(line), flush=True)
+            log(f"rank {rank}: watchdog: giving up, exit status {EXIT_STALLED}")
+            os._exit(EXIT_STALLED)
+        watchdog = threading.Timer(float(os.environ.get("RT_BENCH_WATCHDOG_S", "360")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     from raytracer_amd import abi, host
-    resx, resy = frame_for(n) if not dry else (256 * WEAK_FACTORS.get(n, (n, 1))[0], 128 * WEAK_FACTORS.get(n, (n, 1))[1])
+    if dry:
+        sd = bench_scene()                  # only the camera is used
+        resx, resy = 256 * WEAK_FACTORS.get(n, (n, 1))[0], 128 * WEAK_FACTORS.get(n, (n, 1))[1]
+    else:
+        from raytracer_amd import synth
+        t0 = time.perf_counter()
+        sd = synth.mesh_scene(1000, 500, reflect=0.3)
+        resx, resy = frame_for(n)
     npix = resx * resy
     packed = n > 1                      # a rank's tiles leave the kernel as one contiguous buffer (rt_params.packed_output)
     cam = host.camera_for(sd, (resx, resy))
+    scene_s = None
     if not dry:
         gs = host.Scene(sd, device=local_rank)
-        params = host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n,
-                                     packed_output=1 if packed else 0)
+        scene_s = time.perf_counter() - t0
+        params = host.default_params("hw4", spp=HEAD_SPP, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n,
+                                     packed_output=1 if packed else 0, **DRT_KW)
         stream = torch.cuda.current_stream()
         sp = C.c_void_p(stream.cuda_stream)
     if packed:
         # pixel lists in the kernel's order (rt_render_pixel_list; -1 = a slot outside the frame)
-        lists = [host.pixel_list(cam, host.default_params("hw4", primary_only=1, tile_size=TILE, tile_rank=r, tile_nranks=n))
-                 for r in range(n)]
+        lists = [host.pixel_list(cam, host.default_params("hw4", tile_size=TILE, tile_rank=r, tile_nranks=n)) for r in range(n)]
         counts = [int(l.size) for l in lists]
         my_pix = None
     else:
@@ -814,7 +1019,6 @@ def main():
         counts = [len(rank_pixel_index(resx, resy, r, n)) for r in range(n)] if n > 1 else [npix]
     maxc = max(counts)
     frame = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
-    hit_ids = torch.zeros(npix, dtype=torch.int32, device=dev) if (n == 1 and not dry) else None
     sendbuf = [torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     recv = [[torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(n)] for _ in range(2)] if (n > 1 and rank == 0) else None
     final = torch.zeros((npix, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -823,7 +1027,7 @@ def main():
     else:
         all_pix = [torch.from_numpy(rank_pixel_index(resx, resy, r, n)).to(dev) for r in range(n)] if (n > 1 and rank == 0) else None
     st = abi.rt_stats()
-    tot = dict(rays=0, closest_ms=0.0, any_ms=0.0, closest_launches=0, closest_rays=0, any_launches=0, shadow_rays=0)
+    tot = dict(rays=0)
     pending = [None, None]
 
     def step(i, timed):
@@ -844,17 +1048,12 @@ def main():
             if packed and pending[b] is not None:     # the kernel writes the send buffer itself: its gather of two steps
                 pending[b].wait()                     # ago must have left
                 pending[b] = None
-            # timed steps ask for no rt_stats: the frames queue on the stream back to back (rt_stats needs a device -> host
-            # copy and a synchronisation per frame).  Every step renders the same frame, so its ray counts are those of the
-            # instrumented frames that follow the timed region.
+            # timed steps ask for no rt_stats (no event bookkeeping, no counter read-back).  Every step renders the same
+            # frame, so its ray counts are those of the instrumented frames that follow the timed region.
             abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(params), sendbuf[b].data_ptr() if packed else frame.data_ptr(),
-                                         hit_ids.data_ptr() if (timed == "stats" and hit_ids is not None) else None,
-                                         C.byref(st) if timed == "stats" else None, sp))
+                                         None, C.byref(st) if timed == "stats" else None, sp))
             if timed == "stats":
-                tot["rays"] += st.rays_primary + st.rays_shadow
-                tot["closest_ms"] += st.trace_closest_ms; tot["any_ms"] += st.trace_any_ms
-                tot["closest_launches"] += st.trace_closest_launches; tot["closest_rays"] += st.rays_primary
-                tot["any_launches"] += st.trace_any_launches; tot["shadow_rays"] += st.rays_shadow
+                tot["rays"] += st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
         if n > 1:
             if pending[b] is not None:                # the buffer pair of two steps ago must have left
                 pending[b].wait()
@@ -902,10 +1101,10 @@ def main():
         drain()
     sync()
     dt = time.perf_counter() - t0
-    # the same frame again with rt_stats, for the ray counts and the per-kernel HIP-event times of the roofline
+    # the same frame again with rt_stats, for the ray counts
     nstat = 0
     if not dry:
-        nstat = max(1, min(args.steps, 20))
+        nstat = max(1, min(args.steps, 2))
         for i in range(nstat):
             step(i, "stats")
         if n > 1:
@@ -935,68 +1134,60 @@ def main():
                 ok = ok and sum(int((all_pix[r] >= 0).sum()) for r in range(n)) == npix      # every pixel has exactly one owner
             else:
                 ok = True
-            print(json.dumps({"dry_run": True, "n_gpus": n, "frame": [resx, resy], "assembled_ok": ok,
-                              "pixels_per_rank": counts}))
+            out = {"dry_run": True, "n_gpus": n, "frame": [resx, resy], "assembled_ok": ok, "pixels_per_rank": counts}
         if n > 1:
+            stall = os.environ.get("RT_BENCH_TEST_STALL_RANK")       # tests only: this rank never reaches the last barrier
+            if stall is not None and int(stall) == rank:
+                time.sleep(3600)
+            dist.barrier()
+            watchdog.cancel()
             dist.destroy_process_group()
-        return
+        if rank == 0:
+            print(json.dumps(out))
+        return 0
 
-    out = None
+    failed = []
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = total_rays / dt / 1e6
-        out = {"metric": "Mrays/s (KD-tree traversal, primary + shadow rays)", "value": value, "unit": "Mrays/s",
-               "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+        out = {"metric": "Mrays/s (distributed ray tracing: primary + shadow + reflection + refraction rays)", "value": value,
+               "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: bundled monkey scene (970 triangles, 138 KD nodes), "
-                                      f"{resx}x{resy}, primary + shadow rays only, reflect=refract=0",
-                          "frame": [resx, resy], "rays_per_step": total_rays / args.steps,
+               "config": {"workload": drt_workload(sd, (resx, resy), HEAD_SPP), "frame": [resx, resy], "spp": HEAD_SPP,
+                          "rays_per_step": total_rays / args.steps, "scene_generate_build_upload_s": scene_s,
                           "parallelism": f"tiles{TILE}x{TILE} round-robin over {n} GPU(s), scene replicated, gather to rank 0"}}
         if rehearse:
             out["config"]["rehearsal"] = "gloo backend, every rank on GPU 0, collectives staged through the host: NOT a measurement"
         if n > 1:
             # the frame rank 0 assembled from the ranks' last gather against the same frame rendered whole on rank 0
-            pw = host.default_params("hw4", primary_only=1)
+            pw = host.default_params("hw4", spp=HEAD_SPP, **DRT_KW)
             abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(pw), frame.data_ptr(), None, None, sp))
             torch.cuda.synchronize()
-            out["config"]["assembled_frame_equals_one_gpu_frame"] = bool(torch.equal(final.view(-1), frame))
-        else:
-            # parity: the 4K frame's primary hit ids against the reference's own digest (tests/golden/monkey4k_hits_digest.npz,
-            # made by oracle/gen_golden.py from the unmodified SimpleMeshRayTrace through ID-colour materials)
-            try:
-                g = np.load(os.path.join(ROOT, "tests", "golden", "monkey4k_hits_digest.npz"))
-                ids = hit_ids.cpu().numpy()
-                dig = hashlib.sha256(np.ascontiguousarray(ids.reshape(resy, resx).T.astype("<i4")).tobytes()).hexdigest()   # the reference's x-major order
-                want_dig = str(g["sha256_ids_xy"].item())
-                out["parity"] = dict(frame=[resx, resy], hit_id_sha256=dig, reference_sha256=want_dig,
-                                     parity_ok=bool(want_dig is not None and dig == want_dig))
-            except Exception as e:
-                out["parity"] = dict(error=f"{type(e).__name__}: {e}", parity_ok=False)
-        # roofline of the dominant kernel: counters of the committed profile, time live
-        pr = host.default_params("hw4", primary_only=1, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n)
-        stw = render_work(gs, cam, pr, sp, torch)
-        launches = max(1, tot["closest_launches"])
-        avg_ms = tot["closest_ms"] / launches
-        fused = tot["any_launches"] == 0 and tot["shadow_rays"] > 0       # the whole frame is ONE kernel (k_primary_only)
-        alg_c, wave_c = traversal_bytes(stw.closest_work, stw.rays_primary)
-        alg_a, wave_a = traversal_bytes(stw.any_work, stw.rays_shadow, out_bytes=1)
-        kernel = "k_primary_only" if fused else "k_trace_closest_bvh"
-        out["roofline"] = make_roofline(
-            "monkey_4k", kernel, avg_ms, (tot["closest_rays"] + (tot["shadow_rays"] if fused else 0)) / launches,
-            alg_c + (alg_a if fused else 0.0), wave_c + (wave_a if fused else 0.0),
-            box_tests_per_ray=stw.closest_work[0] / max(1, stw.rays_primary), tri_records_per_ray=stw.closest_work[1] / max(1, stw.rays_primary),
-            exact_tri_tests_per_ray=stw.closest_work[2] / max(1, stw.rays_primary),
-            shadow_box_tests_per_ray=stw.any_work[0] / max(1, stw.rays_shadow), shadow_tri_records_per_ray=stw.any_work[1] / max(1, stw.rays_shadow),
-            note=("one fused kernel traces the primary AND the shadow rays (generate, closest hit, any hit, shade, pixel). " if fused else "") +
-                 "The scene (87 KB) lives in the scalar cache / L2: HBM sees the frame that is written and little else, so the "
-                 "kernel is priced against instruction issue; see DESIGN.md 4.1d / 5")
-        if "headline" in cpu:
-            out["cpu_baseline"] = cpu["headline"]
+            same = bool(torch.equal(final.view(-1), frame))
+            out["config"]["assembled_frame_equals_one_gpu_frame"] = same
+            if not same:
+                failed.append("headline: assembled frame differs from the one-GPU frame")
+        # roofline of the dominant kernel (counters of the committed profile, time live), CPU leg, parity sample: on this
+        # rank's share of the frame (N = 1: the whole frame)
+        try:
+            pa = host.default_params("hw4", spp=HEAD_SPP, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n, **DRT_KW)
+            an = drt_analysis(torch, gs, sd, cam, pa, sp, with_cpu=not args.no_cpu_baseline)
+            out["roofline"] = an["roofline"]
+            if an["cpu_baseline"]:
+                out["cpu_baseline"] = an["cpu_baseline"]
+            if an["parity"]:
+                out["parity"] = an["parity"]
+                if not an["parity"]["parity_sample_ok"]:
+                    failed.append("headline: parity sample")
+            out["config"].update(rays=an["counts"], passes=an["passes"], frame_kernel_ms=an["frame_ms"])
+        except Exception as e:
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+            failed.append("headline: instrumented frames")
         if n == 1 and not args.no_knn:
             sec = {}
-            for name, fn in (("knn", lambda: knn_secondary(gs, torch, args.knn_photons, args.knn_queries)),
+            for name, fn in (("monkey_4k", lambda: monkey_secondary(torch, local_rank, cpu=cpu.get("monkey_4k"))),
                              ("mesh_1m", lambda: mesh_secondary(torch, local_rank, cpu=cpu.get("mesh_1m"))),
-                             ("drt_1m", lambda: drt_secondary(torch, local_rank)),
+                             ("knn", lambda: knn_secondary(gs, torch, args.knn_photons, args.knn_queries)),
                              ("photon_frame", lambda: photon_frame_secondary(torch, local_rank)),
                              # BASELINE configuration 4 at its stated size: 10 M + 1 M photons from GPU emission, 1080p
                              ("photon_frame_full", lambda: photon_frame_secondary(torch, local_rank, 10_000_000, 1_000_000, (1920, 1080), tag="photon_frame_full")),
@@ -1009,44 +1200,35 @@ def main():
                     t0 = time.perf_counter()
                     sec[name] = fn()
                     log(f"{name}: {time.perf_counter() - t0:.1f} s")
-                except Exception as e:           # a secondary line must never take the headline down with it
+                except Exception as e:           # a secondary line never takes the headline down with it, but it fails the run
                     sec[name] = {"error": f"{type(e).__name__}: {e}"}
+                    log(f"{name} FAILED: {type(e).__name__}: {e}")
+                if line_failed(sec[name]):
+                    failed.append(name)
             out["secondary"] = sec
-    watchdog = None
     if n > 1 and not args.no_knn:
-        # the secondary lines at N > 1 contain collectives; if a rank dies inside one the others would wait for ever and the
-        # headline would be lost with them.  After 6 minutes every rank gives up: rank 0 prints the headline as it stands.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                out["secondary"] = {"error": "the N > 1 secondary lines did not finish within 360 s"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(360.0, give_up)
-        watchdog.daemon = True
-        watchdog.start()
         sec = {}
         # the metric's second half at N GPUs: every rank answers its own share of the radiance lookups (the queries
         # follow their pixels, the photon map is replicated, no exchange: SURVEY 8e), weak scaling like the frame
-        try:
-            r = knn_secondary(gs, torch, args.knn_photons, args.knn_queries, steps=3, with_cpu=False)
-            ms = r["ms_per_step"]
-        except Exception as e:
-            log(f"rank {rank}: kNN line failed: {type(e).__name__}: {e}")
-            r, ms = None, float("inf")
-        ms = coll.max_float(ms, dev)
-        if rank == 0:
-            if r is not None and ms != float("inf"):
-                r["value"] = n * args.knn_queries / (ms * 1e-3)
-                r["ms_per_step"] = ms; r["n_gpus"] = n; r["scaling"] = "weak"
-                r["config"]["queries"] = n * args.knn_queries
-                r["note"] = "aggregate over the ranks: each answers its own queries on its replica of the map; time = slowest rank"
-                sec["knn"] = r
-            else:
-                sec["knn"] = {"error": "a rank failed"}
+        if not only or "knn" in only:
+            try:
+                r = knn_secondary(gs, torch, args.knn_photons, args.knn_queries, steps=3, with_cpu=False)
+                ms = r["ms_per_step"]
+            except Exception as e:
+                log(f"rank {rank}: kNN line failed: {type(e).__name__}: {e}")
+                r, ms = None, float("inf")
+            ms = coll.max_float(ms, dev)
+            if rank == 0:
+                if r is not None and ms != float("inf"):
+                    r["value"] = n * args.knn_queries / (ms * 1e-3)
+                    r["ms_per_step"] = ms; r["n_gpus"] = n; r["scaling"] = "weak"
+                    r["config"]["queries"] = n * args.knn_queries
+                    r["note"] = "aggregate over the ranks: each answers its own queries on its replica of the map; time = slowest rank"
+                    sec["knn"] = r
+                else:
+                    sec["knn"] = {"error": "a rank failed"}
         # the configurations that are meant to scale, strong scaling (every rank runs them: collectives inside)
-        for name, fn in (("drt_1m_strong", lambda: drt_strong(torch, coll, rank, n, local_rank)),
+        for name, fn in (("drt_1m_strong", lambda: drt_strong(torch, coll, rank, n, local_rank, gs=gs, sd=sd)),
                          ("emission_sharded", lambda: emission_sharded(torch, dist, coll, rank, n, local_rank))):
             if only and name not in only:
                 continue
@@ -1059,14 +1241,22 @@ def main():
                 sec[name] = res
         if rank == 0:
             out["secondary"] = sec
+            failed += [k for k, v in sec.items() if line_failed(v)]
     if n > 1:
         dist.barrier()
-        if watchdog is not None:
-            watchdog.cancel()
+        watchdog.cancel()
         dist.destroy_process_group()
+    rc = 0
     if rank == 0:
+        if failed:
+            out["failed_lines"] = failed
+            rc = EXIT_LINE_FAILED
         print(json.dumps(out), flush=True)
+    if n > 1 and not dry:
+        # every rank leaves with the same status
+        pass
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

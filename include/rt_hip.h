@@ -237,7 +237,10 @@ typedef struct rt_photon {
 /* ---- library ------------------------------------------------------------- */
 
 /* Probe the HIP runtime; returns the number of gfx950 devices visible (>=1) or
- * a negative error.  ndev_wanted > visible count is an error. (no counterpart) */
+ * a negative error.  ndev_wanted > visible count is an error. (no counterpart)
+ * Also resolves rt_photon_irradiance_noalloc_dev's fixed workspace on the FIRST
+ * ndev_wanted gfx950 devices (that creates a HIP context and loads the code
+ * object there); devices the caller did not ask for are only probed.           */
 int rt_init(int ndev_wanted);
 const char* rt_last_error(void);
 int rt_abi_version(void);
@@ -385,7 +388,12 @@ int rt_photonmap_build(rt_scene* s, int which, rt_photon* photons, int64_t n, fl
  * then ScalePhotonPower and the device image.  d_photons[0..n] (slot 0 unused) comes back in the reference's heap order,
  * byte for byte what rt_photonmap_build leaves in its host array.  Synchronises the stream (one read-back per tree level).
  * rt_photonmap_build itself takes this path through a temporary device copy from 65536 photons up (RT_PHOTON_BUILD=host
- * or =device forces one or the other).                                                                              */
+ * or =device forces one or the other).
+ * Memory and failure: the build holds about 220 B per photon of device memory at its peak (the caller's array, a copy in
+ * emission order, the balance's index / key lists, both heaps and the image); the scene's previous map `which` is
+ * released BEFORE the build starts so that the two never coexist.  If the call fails (RT_E_NOMEM, a HIP error) the
+ * scene is left with NO map `which` (queries return RT_E_STATE until a build or upload succeeds) and the contents of
+ * d_photons[0..n] are undefined -- they may already be permuted or scaled; the caller re-creates them to retry.     */
 int rt_photonmap_build_dev(rt_scene* s, int which, rt_photon* d_photons, int64_t n, float power_scale, void* hip_stream);
 
 /* One build per node (no counterpart: the reference is one process).  With the map replicated on every GPU, one rank
@@ -459,8 +467,9 @@ int rt_photon_irradiance_dev(rt_scene* s, int which, const float* d_pos3,
  * strict kernel) is a fixed 16 MiB array inside the library's code object instead of a grow-only allocation of the
  * scene, and the call issues no hipMalloc / hipFree or any allocating routine.  Limits and rules:
  *   - at most RT_NOALLOC_MAX_QUERIES queries per call (RT_E_LIMIT beyond; split the call);
- *   - rt_init() resolves the array's address on every gfx950 device; without it the first call on a device does
- *     (one hipGetSymbolAddress), so call rt_init before capturing a graph;
+ *   - the array's address is resolved (one hipGetSymbolAddress per device) by rt_init for the first ndev_wanted gfx950
+ *     devices and by rt_scene_create for the scene's device, so a caller that created its scene before it begins a graph
+ *     capture never resolves under capture; the call itself only looks the address up;
  *   - every GPU has ONE such array, shared by all scenes and streams on it: calls that overlap in time on one GPU
  *     race on it (issue them on one stream, or order them with events).  The array keeps the last call's contents;
  *     the call clears what must start at zero on its stream.                                                     */

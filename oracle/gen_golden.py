@@ -274,6 +274,34 @@ def gen_final():
     print("final golden: eye pixels hit", int(ha.sum()), "see light", int(sl.sum()), "shadowed", int(sh.sum()))
 
 
+def gen_emission():
+    """The reference's own emission loops (final.cpp:1053-1123), run once by PhotonMappingImageSynthesis with a 0 x 0 camera
+    in a FRESH process (final.cpp's copy of the serial engine starts at the pinned seed): position and direction of every
+    emission, noted on their way into PhotonTrace / PhotonTraceCaustics (oracle/ref_harness_final.cpp, --wrap observers)."""
+    import tempfile
+    sd = scene.parse_scene_file(os.path.join(G, "final_input.txt"), flavour="final")
+    R = ol.ref_final_build_scene(sd)
+    cs = np.array([0.2, -0.3, 0.45, 0.2], f32); R.reff_add_caustic_sphere(cs.ctypes.data)
+    ng, nc = C.c_int64(0), C.c_int64(0)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            R.reff_run_emission_loops(C.byref(ng), C.byref(nc))
+        finally:
+            os.chdir(cwd)
+    out = dict(seed=R.reff_seed(), n_global=ng.value, n_caustic=nc.value)
+    for which, n in ((0, ng.value), (1, nc.value)):
+        pd = np.zeros((n, 6), f32); sb = np.zeros(n, np.int32)
+        R.reff_emission_log(which, pd.ctypes.data, sb.ctypes.data)
+        out[f"posdir{which}"] = pd; out[f"stored_before{which}"] = sb
+    # kept small: every global emission's ray is 24 B; the first 40 000 global + all caustic emissions pin the loop
+    keep = min(ng.value, 40000)
+    out["posdir0"] = out["posdir0"][:keep]; out["stored_before0"] = out["stored_before0"][:keep]
+    np.savez_compressed(os.path.join(G, "emission_golden.npz"), **out)
+    print("emission golden: global emissions", ng.value, "(kept", keep, ") caustic emissions", nc.value)
+
+
 def gen_quantise():
     """AddPhoton's direction bytes (photon.cpp:846,869-882) for 60 000 random directions."""
     R = ol.ref_photon()
@@ -291,13 +319,19 @@ def gen_quantise():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
-    ap.add_argument("--only", default="", help="comma list: monkey,units,photon,final,quantise")
+    ap.add_argument("--only", default="", help="comma list: monkey,units,photon,final,quantise,emission")
     a = ap.parse_args()
     if not ol.have_ref():
         sys.exit("oracle/_ref is missing: run `make -C oracle ref` in the build container")
     text = open(os.path.join(G, "monkey.txt")).read()
     sd = scene.parse_scene_text(text)
     only = set(a.only.split(",")) if a.only else None
+    if only == {"emission"}:
+        gen_emission()
+        sys.exit(0)
+    if not only or "emission" in only:        # needs the reference's engine untouched: a process of its own
+        import subprocess
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--only", "emission"], check=True)
     if not only or "monkey" in only: gen_monkey(sd, text, a.big)
     if not only or "units" in only: gen_units()
     if not only or "photon" in only: gen_photon()

@@ -14,6 +14,38 @@
 #include "final.cpp"        /* found through -I, never copied */
 #undef main
 
+/* Observation of the emission loops (final.cpp:1053-1123).  They are inline in PhotonMappingImageSynthesis and hand their
+ * rays straight to PhotonTrace / PhotonTraceCaustics (photon.cpp, another translation unit).  The library is linked with
+ * -Wl,--wrap=<the two mangled names> (oracle/Makefile), so THIS file's calls to them arrive at the two functions below,
+ * which note the depth-0 arguments and call the real, unmodified functions (__real_...); photon.cpp's own recursive
+ * calls are not affected.  No reference file is edited or replaced. */
+#define PT_SYM  "_Z11PhotonTraceR9PhotonMapRSt6vectorIP10SimpleMeshSaIS3_EE4vec3S7_ifS7_"
+#define PTC_SYM "_Z19PhotonTraceCausticsR9PhotonMapRSt6vectorIP10SimpleMeshSaIS3_EE4vec3S7_ifS7_bS6_"
+void real_PhotonTrace(PhotonMap&, vector<SimpleMesh*>&, vec3, vec3, int, float, vec3) asm("__real_" PT_SYM);
+void wrap_PhotonTrace(PhotonMap&, vector<SimpleMesh*>&, vec3, vec3, int, float, vec3) asm("__wrap_" PT_SYM);
+void real_PhotonTraceCaustics(PhotonMap&, vector<SimpleMesh*>&, vec3, vec3, int, float, vec3, bool, vector<SimpleMesh*>&) asm("__real_" PTC_SYM);
+void wrap_PhotonTraceCaustics(PhotonMap&, vector<SimpleMesh*>&, vec3, vec3, int, float, vec3, bool, vector<SimpleMesh*>&) asm("__wrap_" PTC_SYM);
+static std::vector<float> g_emit_log[2];        /* per loop: pos xyz, dir xyz of every emission */
+static std::vector<int> g_emit_stored[2];       /* photons stored in the map when the emission was made */
+static bool g_emit_record = false;
+void wrap_PhotonTrace(PhotonMap& m, vector<SimpleMesh*>& v, vec3 ori, vec3 dir, int depth, float nr, vec3 col) {
+    if (g_emit_record && depth == 0) {
+        for (int k = 0; k < 3; k++) g_emit_log[0].push_back(ori[k]);
+        for (int k = 0; k < 3; k++) g_emit_log[0].push_back(dir[k]);
+        g_emit_stored[0].push_back(m.storedPhotonNum);
+    }
+    real_PhotonTrace(m, v, ori, dir, depth, nr, col);
+}
+void wrap_PhotonTraceCaustics(PhotonMap& m, vector<SimpleMesh*>& v, vec3 ori, vec3 dir, int depth, float nr, vec3 col, bool flag,
+                              vector<SimpleMesh*>& cm) {
+    if (g_emit_record && depth == 0) {
+        for (int k = 0; k < 3; k++) g_emit_log[1].push_back(ori[k]);
+        for (int k = 0; k < 3; k++) g_emit_log[1].push_back(dir[k]);
+        g_emit_stored[1].push_back(m.storedPhotonNum);
+    }
+    real_PhotonTraceCaustics(m, v, ori, dir, depth, nr, col, flag, cm);
+}
+
 namespace {
 struct Quiet {
     std::streambuf* old;
@@ -159,6 +191,25 @@ void reff_eye_trace(const float* ori, const float* dir, int depth, float nr, int
         rgb[3 * i] = c[0]; rgb[3 * i + 1] = c[1]; rgb[3 * i + 2] = c[2];
         hit_any[i] = rayHitAnything ? 1 : 0;
     }
+}
+
+/* The reference's own emission loops, run once: PhotonMappingImageSynthesis (final.cpp:1045-1209) with a 0 x 0 camera,
+ * so that its pixel loop has no iteration (it still writes an empty colorOutput.ppm into the current directory: call
+ * this from a scratch directory).  Draws come from final.cpp's copy of the serial engine, which must be fresh (nothing
+ * else of this library called before in the process) for the fixture to start at the seed.  Returns the emission counts. */
+void reff_run_emission_loops(int64_t* n_global, int64_t* n_caustic) {
+    Quiet q;
+    g_emit_log[0].clear(); g_emit_log[1].clear(); g_emit_stored[0].clear(); g_emit_stored[1].clear();
+    g_emit_record = true;
+    Camera cam = camera;
+    cam.resX = 0; cam.resY = 0;
+    PhotonMappingImageSynthesis(cam);
+    g_emit_record = false;
+    *n_global = (int64_t)g_emit_stored[0].size(); *n_caustic = (int64_t)g_emit_stored[1].size();
+}
+void reff_emission_log(int which, float* posdir6, int32_t* stored_before) {
+    memcpy(posdir6, g_emit_log[which].data(), g_emit_log[which].size() * sizeof(float));
+    memcpy(stored_before, g_emit_stored[which].data(), g_emit_stored[which].size() * sizeof(int));
 }
 
 }  // extern "C"

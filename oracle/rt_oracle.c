@@ -6,6 +6,7 @@
  * order follows the reference expression by expression; build with
  * -ffp-contract=off on x86-64 (SSE2: no excess precision).
  */
+#include <pthread.h>
 #include "rt_oracle.h"
 #include <math.h>
 #include <stdlib.h>
@@ -96,11 +97,25 @@ static kdnode* new_node(void) {
     return n;
 }
 
-/* ---- KDNode::BuildKD, hw4.cpp:393-490 ----------------------------------- */
+/* ---- KDNode::BuildKD, hw4.cpp:393-490 -----------------------------------
+ * The two recursive calls at :475-476 work on disjoint nodes and share only the two statistics `builded` and `maxDepth`
+ * (hw4.cpp:391-392, updated atomically here), so above a size threshold the left call runs on a thread of its own: the
+ * tree is the same node for node, a 10 M-triangle scene takes ~10 s instead of ~60 (the GPU suite and bench.py build it
+ * to check hit ids at that size).  ORC_KD_THREADS=0 keeps everything on the calling thread. */
+static void build_kd(orc_scene* s, kdnode* n, int depth);
+typedef struct { orc_scene* s; kdnode* n; int depth; } kd_job;
+static void* kd_thread(void* p) { kd_job* j = (kd_job*)p; build_kd(j->s, j->n, j->depth); return NULL; }
+static int kd_fork_depth(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ORC_KD_THREADS"); v = (e && atoi(e) == 0) ? 0 : 4; }     /* <= 2^4 threads */
+    return v;
+}
+
 static void build_kd(orc_scene* s, kdnode* n, int depth) {
     n->layer = depth;
-    if (depth > s->max_depth) s->max_depth = depth;
-    s->builded++;
+    for (int32_t cur = __atomic_load_n(&s->max_depth, __ATOMIC_RELAXED); depth > cur; )
+        if (__atomic_compare_exchange_n(&s->max_depth, &cur, depth, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+    __atomic_fetch_add(&s->builded, 1, __ATOMIC_RELAXED);
     calc_bound(s, n);
     int ax = n->split_axis;
     int64_t np = n->nprims;
@@ -130,8 +145,14 @@ static void build_kd(orc_scene* s, kdnode* n, int depth) {
     if ((float)match < (float)L->nprims / n->model_scale &&
         (float)match < (float)R->nprims / n->model_scale) {
         /* interior: its own list is never read again */
-        build_kd(s, L, depth + 1);
-        build_kd(s, R, depth + 1);
+        pthread_t th; kd_job job = { s, L, depth + 1 };
+        if (depth < kd_fork_depth() && np > 100000 && pthread_create(&th, NULL, kd_thread, &job) == 0) {
+            build_kd(s, R, depth + 1);
+            pthread_join(th, NULL);
+        } else {
+            build_kd(s, L, depth + 1);
+            build_kd(s, R, depth + 1);
+        }
     } else {
         calc_bound(s, L); calc_bound(s, R);
         L->layer = R->layer = depth + 1;
@@ -1180,6 +1201,31 @@ static void photon_trace_caustics(ectx* c, v3 ori, v3 dir, int depth, float curr
     }
 }
 
+/* The emission ray of one pass of the `while` bodies at final.cpp:1057-1076 / :1090-1110 from four draws:
+ * a point of the light's rectangle and a cosine-distributed direction about (0,-1,0).
+ * final.cpp:1075 calls std::cos(float) = glibc's cosf, which is not correctly rounded (0.56 ulp) and has FMA and
+ * non-FMA variants chosen at run time: a restatement through it is not reproducible between hosts, let alone on the
+ * device.  The build-defined emission (counter-based draws: orc_emit_photons, kernels_emit.hip) therefore evaluates the
+ * cosine and sine in double and rounds -- the correctly rounded float in all but ~1e-8 of the cases.  `use_cosf` selects
+ * the reference's own calls instead: that variant is what tests/test_oracle_golden.py pins against the reference's
+ * emission loop (emission_golden.npz), and what tests/test_gpu_emit.py's second, few-ulp assertion compares the device
+ * with.  Parity of the emission DIRECTION with the reference's cosf is thus measured there, not asserted here. */
+static int g_emission_cosf = 0;
+void orc_set_emission_cosf(int on) { g_emission_cosf = on; }
+
+static void emission_ray(const rt_light* l, float offset_x, float offset_y, float u1, float u2, v3* pos_out, v3* dir_out) {
+    v3 d1 = vmuls(vload(l->dir1), l->size1), d2 = vmuls(vload(l->dir2), l->size2);
+    *pos_out = vadd(vsub(vadd(vsub(vload(l->pos), vmuls(d1, 0.5f)), vmuls(d1, offset_x)), vmuls(d2, 0.5f)), vmuls(d2, offset_y));
+    v3 nl = V(0, -1.0f, 0);
+    float r1 = (float)(2 * PM_PI * u1), r2 = u2, r2s = sqrtf(r2);
+    v3 w = nl, u = vnorm(vcross(V(1.0f, 0, 0), w)), v = vcross(w, u);
+    float cr1, sr1;
+    if (g_emission_cosf) { cr1 = cosf(r1); sr1 = sinf(r1); }
+    else { cr1 = (float)cos((double)r1); sr1 = (float)sin((double)r1); }
+    v3 d = vadd(vadd(vmuls(vmuls(u, cr1), r2s), vmuls(vmuls(v, sr1), r2s)), vmuls(w, sqrtf(1 - r2)));
+    *dir_out = vnorm(d);
+}
+
 /* one pass of the `while` bodies at final.cpp:1057-1086 / :1090-1119 per emission index;
  * photons come out in emission order.  Returns the number stored (may exceed cap: then only
  * the first cap were written). */
@@ -1190,19 +1236,9 @@ int64_t orc_emit_photons(orc_scene* s, const rt_emit_params* e, int64_t first, i
     for (int64_t k = first; k < first + count; k++) {
         c.key_a = ((uint64_t)e->which << 60) | (uint64_t)k; c.draw = 0;
         float offset_x = edraw(&c), offset_y = edraw(&c);
-        v3 d1 = vmuls(vload(l->dir1), l->size1), d2 = vmuls(vload(l->dir2), l->size2);
-        v3 pos = vadd(vsub(vadd(vsub(vload(l->pos), vmuls(d1, 0.5f)), vmuls(d1, offset_x)), vmuls(d2, 0.5f)), vmuls(d2, offset_y));
-        v3 nl = V(0, -1.0f, 0);
-        float r1 = (float)(2 * PM_PI * edraw(&c)), r2 = edraw(&c), r2s = sqrtf(r2);
-        v3 w = nl, u = vnorm(vcross(V(1.0f, 0, 0), w)), v = vcross(w, u);
-        /* final.cpp:1071 calls std::cos(float) = glibc's cosf, which is not correctly rounded (0.56 ulp) and has FMA and
-         * non-FMA variants chosen at run time: a restatement through it is not reproducible between hosts, let alone on
-         * the device.  This emission is build-defined (counter-based draws), so it evaluates the cosine in double and
-         * rounds -- the correctly rounded float in all but ~1e-8 of the cases -- as kernels_emit.hip does.  (The pinning
-         * entry point orc_photon_trace_serial takes its emission rays from the reference itself.) */
-        const float cr1 = (float)cos((double)r1), sr1 = (float)sin((double)r1);
-        v3 d = vadd(vadd(vmuls(vmuls(u, cr1), r2s), vmuls(vmuls(v, sr1), r2s)), vmuls(w, sqrtf(1 - r2)));
-        d = vnorm(d);
+        float u1 = edraw(&c), u2 = edraw(&c);
+        v3 pos, d;
+        emission_ray(l, offset_x, offset_y, u1, u2, &pos, &d);
         v3 color = vload(e->power);
         if (e->which == RT_PMAP_GLOBAL) photon_trace(&c, pos, d, 0, e->start_nr, color);
         else photon_trace_caustics(&c, pos, d, 0, e->start_nr, color, 0);
@@ -1223,6 +1259,20 @@ int64_t orc_photon_trace_serial(orc_scene* s, const rt_emit_params* e, const flo
         else photon_trace_caustics(&c, vload(pos3 + 3 * i), vload(dir3 + 3 * i), 0, e->start_nr, vload(e->power), 0);
     }
     return c.n;
+}
+
+/* the emission rays of final.cpp:1057-1076 with the four draws of every emission taken from the reference's serial
+ * engine (final.cpp's own copy of mRandom, photon.h:16-18: offset_x, offset_y, r1, r2 in that order); the russian-roulette
+ * draws of PhotonTrace come from photon.cpp's copy and do not interleave.  Pinned against emission_golden.npz. */
+void orc_emission_rays_serial(orc_scene* s, int light, int64_t n, uint32_t* lcg_state, float* pos3, float* dir3) {
+    const rt_light* l = &s->lights[light];
+    for (int64_t i = 0; i < n; i++) {
+        float ox = orc_minstd_next(lcg_state), oy = orc_minstd_next(lcg_state);
+        float u1 = orc_minstd_next(lcg_state), u2 = orc_minstd_next(lcg_state);
+        v3 pos, d;
+        emission_ray(l, ox, oy, u1, u2, &pos, &d);
+        vstore(pos3 + 3 * i, pos); vstore(dir3 + 3 * i, d);
+    }
 }
 
 void orc_trace_irradiance(orc_scene* s, const rt_params* p, const rt_photon* gheap, int64_t gn,

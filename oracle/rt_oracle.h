@@ -112,6 +112,10 @@ void orc_eye_trace(orc_scene* s, const rt_camera* cam, const rt_params* p, const
                    int64_t n, uint32_t* lcg_state /* NULL: counter RNG */, float* rgb, uint8_t* hit_any);
 int64_t orc_emit_photons(orc_scene* s, const rt_emit_params* e, int64_t first, int64_t count,
                          rt_photon* out, int64_t cap);
+/* emission direction through the reference's own cosf / sinf (final.cpp:1075) instead of the build-defined rounded double */
+void orc_set_emission_cosf(int on);
+/* the emission rays of final.cpp:1057-1076 from the reference's serial engine (pinned by tests/golden/emission_golden.npz) */
+void orc_emission_rays_serial(orc_scene* s, int light, int64_t n, uint32_t* lcg_state, float* pos3, float* dir3);
 
 #ifdef __cplusplus
 }

@@ -130,10 +130,13 @@ int rt_init(int ndev_wanted) {
     for (int d = 0; d < n; ++d) good += is_gfx950(d) ? 1 : 0;
     if (good == 0) return rt_fail(RT_E_NODEVICE, "no gfx950 device among %d HIP devices", n);
     if (ndev_wanted > good) return rt_fail(RT_E_NODEVICE, "%d devices wanted, %d gfx950 visible", ndev_wanted, good);
-    // the fixed workspace of rt_photon_irradiance_noalloc_dev: resolve its address on every usable device now, so that
-    // the entry point itself has nothing to set up (noalloc.hip)
-    for (int d = 0; d < n; ++d)
-        if (is_gfx950(d)) { const int rc = rt_noalloc_setup(d); if (rc) return rc; }
+    // the fixed workspace of rt_photon_irradiance_noalloc_dev: resolve its address now on the devices the caller says it
+    // will use -- the first `ndev_wanted` gfx950 devices -- so that the entry point itself has nothing to set up
+    // (noalloc.hip).  Resolving it creates a HIP context and loads the code object (with the 16 MiB array) on that device,
+    // so it is NOT done for devices the caller did not ask for: a rank that calls rt_init(1) on an 8-GPU node touches one
+    // GPU.  rt_scene_create does the same for its scene's device, and the entry point resolves lazily as a last resort.
+    for (int d = 0, done = 0; d < n && done < ndev_wanted; ++d)
+        if (is_gfx950(d)) { const int rc = rt_noalloc_setup(d); if (rc) return rc; ++done; }
     return good;
 }
 
@@ -176,6 +179,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->device = dev;
     DeviceGuard g(dev);
     if (!g.ok) { delete s; return rt_fail(RT_E_NODEVICE, "hipSetDevice(%d) failed", dev); }
+    // rt_photon_irradiance_noalloc_dev's fixed workspace on this scene's device (a look-up if rt_init already did it): a
+    // caller that captures a HIP graph creates its scene before the capture, so the entry point never resolves under capture
+    { const int rcn = rt_noalloc_setup(dev); if (rcn) { delete s; return rcn; } }
 
     std::vector<DevMaterial> mats((size_t)d->nmaterial);
     for (int i = 0; i < d->nmaterial; ++i) {

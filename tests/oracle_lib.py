@@ -75,6 +75,8 @@ def oracle():
         L.orc_minstd_seed.argtypes = [C.c_uint32]
         L.orc_photon_trace_serial.restype = i64
         L.orc_photon_trace_serial.argtypes = [vp, C.POINTER(abi.rt_emit_params), vp, vp, i64, C.POINTER(C.c_uint32), vp, i64]
+        L.orc_set_emission_cosf.argtypes = [i32]
+        L.orc_emission_rays_serial.argtypes = [vp, i32, i64, C.POINTER(C.c_uint32), vp, vp]
         L.orc_trace_irradiance.argtypes = [vp, C.POINTER(abi.rt_params), vp, i64, vp, vp, i32, f32, i64, vp]
         L.orc_eye_trace.argtypes = [vp, C.POINTER(abi.rt_camera), C.POINTER(abi.rt_params), vp, i64, vp, i64, vp, vp, i32,
                                     f32, i64, C.POINTER(C.c_uint32), vp, vp]
@@ -288,6 +290,8 @@ def ref_final():
         L.reff_photon_trace.argtypes = [i32, vp, vp, vp, f32, i64]
         L.reff_trace_irradiance.argtypes = [vp, vp, i32, f32, i64, vp]
         L.reff_eye_trace.argtypes = [vp, vp, i32, f32, i64, vp, vp]
+        L.reff_run_emission_loops.argtypes = [C.POINTER(i64), C.POINTER(i64)]
+        L.reff_emission_log.argtypes = [i32, vp, vp]
         _RF = L
     return _RF
 

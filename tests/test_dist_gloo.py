@@ -27,7 +27,7 @@ def test_tiles_partition_the_frame(res, nranks):
 def test_weak_scaling_frames():
     for n in (1, 2, 4, 8):
         w, h = bench.frame_for(n)
-        assert w * h == n * 3840 * 2160
+        assert w * h == n * 1920 * 1080          # BASELINE configs[2]: 1080p (x 64 spp) per GPU
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -41,6 +41,29 @@ def test_gather_to_rank0_over_gloo(world):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["assembled_ok"] and j["n_gpus"] == world and sum(j["pixels_per_rank"]) == j["frame"][0] * j["frame"][1]
+
+
+def test_a_stalled_rank_ends_the_run_with_a_nonzero_status():
+    """bench.py's watchdog: a rank that never reaches a collective must not leave the run reading as a success.  Rank 1 is
+    made to stall before the last barrier (RT_BENCH_TEST_STALL_RANK, dry-run only); after RT_BENCH_WATCHDOG_S seconds every
+    rank gives up, rank 0 prints its line marked with `error`, and the launcher's exit status is non-zero."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RT_BENCH_TEST_STALL_RANK="1", RT_BENCH_WATCHDOG_S="20")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29539", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0, "a stalled run exited with status 0"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines and "error" in json.loads(lines[-1]), r.stdout[-2000:]
+    assert "exit status 3" in r.stderr
+
+
+def test_failed_line_detection():
+    assert bench.line_failed({"error": "x"})
+    assert bench.line_failed({"value": 1.0, "parity": {"parity_sample_ok": False}})
+    assert bench.line_failed({"value": 1.0, "config": {"assembled_frame_equals_one_gpu_frame": False}})
+    assert not bench.line_failed({"value": 1.0, "parity": {"parity_sample_ok": True}, "config": {"heap_equals_one_rank_heap": True}})
+    assert not bench.line_failed({"value": 1.0, "parity": None})
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -117,3 +117,38 @@ def test_noalloc_limits_and_errors():
     torch.cuda.synchronize()
     assert torch.equal(g, w) and float(g.abs().max()) > 0.0
     s.close()
+
+
+def test_noalloc_call_allocates_no_device_memory():
+    """The property the entry point exists for: on a FRESH scene (no grow-only workspace yet) the largest call it accepts
+    leaves the device's free memory (hipMemGetInfo) exactly where it was, while the allocating entry point on the same
+    fresh scene lowers it -- so the check can tell the two apart.  Inputs and outputs are allocated before the first
+    reading; nothing else runs on the device in between."""
+    import torch
+    L = abi.load()
+    abi.check(L.rt_init(1))
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    rng = np.random.default_rng(5)
+    a = np.zeros(150_001, abi.photon_dtype)
+    a["position"][1:] = rng.uniform(-0.5, 0.5, (150_000, 3)).astype(np.float32)
+    a["power"][1:] = np.float32(1e-4)
+    a["phi"][1:] = rng.integers(0, 256, 150_000); a["theta"][1:] = rng.integers(0, 256, 150_000)
+    q = abi.RT_NOALLOC_MAX_QUERIES
+    qp = torch.rand((q, 3), dtype=torch.float32, device="cuda") - 0.5
+    qn = torch.ones((q, 3), dtype=torch.float32, device="cuda")
+    out = torch.zeros((q, 3), dtype=torch.float32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    free = {}
+    for name in ("noalloc", "allocating"):
+        s = host.Scene(sd, device=0)
+        s.photonmap_build(abi.RT_PMAP_GLOBAL, a.copy())
+        torch.cuda.synchronize()
+        before = torch.cuda.mem_get_info()[0]
+        fn = L.rt_photon_irradiance_noalloc_dev if name == "noalloc" else L.rt_photon_irradiance_dev
+        abi.check(fn(s.h, 0, qp.data_ptr(), qn.data_ptr(), q, 100, 0.2, out.data_ptr(), st))
+        torch.cuda.synchronize()
+        free[name] = (before, torch.cuda.mem_get_info()[0])
+        assert float(out.abs().max()) > 0.0
+        s.close()
+    assert free["noalloc"][1] == free["noalloc"][0], f"free device memory moved by {free['noalloc'][0] - free['noalloc'][1]} B"
+    assert free["allocating"][1] < free["allocating"][0], "the check has no teeth: the allocating entry point did not allocate"

@@ -6,9 +6,13 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-W="${1:-monkey_4k mesh_1m drt_1m knn_10m photon_frame}"
+W="${1:-monkey_4k mesh_1m drt_1m knn_10m photon_frame photon_frame_full stress_mesh_10m stress_knn_200m}"
 LIMIT="${2:-300}"
+mkdir -p gpurun_out/pmc
+# what the counters belong to: the hash of the kernel sources on this box (bench.py flags counters whose hash is not the live one)
+python3 -c "import bench; print(bench.kernel_source_sha())" > gpurun_out/pmc/kernel_source_sha.txt || exit 1
 for w in $W; do
+  cp gpurun_out/pmc/kernel_source_sha.txt /tmp/sha_$w.txt
   for pass in stats FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
               "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
               "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
@@ -24,4 +28,5 @@ for w in $W; do
     echo "$w $tag rc=$rc $(tail -n 1 "$out/stdout.txt")"
     if [ $rc -ne 0 ]; then tail -n 5 "$out/stderr.txt"; exit $rc; fi
   done
+  cp /tmp/sha_$w.txt gpurun_out/pmc/$w/kernel_source_sha.txt
 done

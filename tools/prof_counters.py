@@ -24,9 +24,23 @@ base = os.path.join(ROOT, "gpurun_out", "pmc")
 outp = os.path.join(ROOT, "profiles", f"{tag}_counters.json")
 out = json.load(open(outp)) if os.path.exists(outp) else {}
 out.pop("_source", None)
+meta = out.setdefault("_meta", {})       # per workload: the commit and kernel-source hash its counters were collected at
+import subprocess
+import time
+try:
+    head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    if subprocess.run(["git", "status", "--porcelain", "raytracer_amd/csrc"], cwd=ROOT, capture_output=True, text=True).stdout.strip():
+        head += "+uncommitted"
+except Exception:
+    head = None
 mean = lambda v: sum(v) / len(v) if v else None
 for wdir in sorted(glob.glob(os.path.join(base, "*"))):
+    if not os.path.isdir(wdir):
+        continue
     w = os.path.basename(wdir)
+    shaf = os.path.join(wdir, "kernel_source_sha.txt")
+    meta[w] = dict(commit=head, kernel_source_sha=open(shaf).read().strip() if os.path.exists(shaf) else None,
+                   reduced=time.strftime("%Y-%m-%d %H:%M"))
     per = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(wdir, "*", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
@@ -77,6 +91,8 @@ for wdir in sorted(glob.glob(os.path.join(base, "*"))):
     out[w] = wout
 json.dump(out, open(outp, "w"), indent=1)
 for w, ks in out.items():
+    if w.startswith("_"):
+        continue
     for k, e in ks.items():
         if e.get("avg_us") and e["avg_us"] * e.get("calls_in_stats_run", 1) > 500:
             d = e.get("derived", {})
