@@ -61,6 +61,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def _jsonable(o):
+    """numpy scalars / arrays that found their way into the line"""
+    if isinstance(o, np.generic):
+        return o.item()
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    return str(o)
+
+
+def dumps(line):
+    return json.dumps(line, default=_jsonable)
+
+
 def bench_scene():
     """monkey.txt with every material's reflect/refract set to 0."""
     from raytracer_amd import scene
@@ -533,6 +546,13 @@ def drt_analysis(torch, gs, sd, cam, p, sp, with_cpu=True):
         "k_trace_any_bvh": (st.trace_any_ms - st.lane_any_ms, st.trace_any_launches - st.lane_any_launches,
                             st.rays_shadow - st.lane_any_rays, [a - b for a, b in zip(stw.any_work, stw.lane_any_work)], 1),
     }
+    if st.path_launches > 0:
+        # the persistent path kernel (RT_OPT_PATH_DEPTH): closest-hit and shadow walks of every deeper recursion level in one
+        # launch; per ray 32 B in + 32 B x box tests + 36 B x triangle records + the result (20 B closest, 1 B shadow)
+        pw = stw.path_work
+        fam["k_paths_bvh_lanes"] = (st.path_ms, st.path_launches, st.path_closest_rays + st.path_shadow_rays,
+                                    [pw[0] + pw[2], pw[1] + pw[3], 0, 0],
+                                    (20.0 * st.path_closest_rays + 1.0 * st.path_shadow_rays) / max(1, st.path_closest_rays + st.path_shadow_rays))
     kernel = max(fam, key=lambda k: fam[k][0])
     ms, launches, krays, work, ob = fam[kernel]
     launches = max(1, launches)
@@ -982,7 +1002,7 @@ def main():
             if rank == 0:
                 line = dict(out) if out else {"metric": "Mrays/s (distributed ray tracing, all ray types)", "value": None, "n_gpus": n}
                 line["error"] = f"the N = {n} run did not finish within its time limit: a rank stalled in a collective"
-                print(json.dumps(line), flush=True)
+                print(dumps(line), flush=True)
             log(f"rank {rank}: watchdog: giving up, exit status {EXIT_STALLED}")
             os._exit(EXIT_STALLED)
         watchdog = threading.Timer(float(os.environ.get("RT_BENCH_WATCHDOG_S", "360")), give_up)
@@ -1143,7 +1163,7 @@ def main():
             watchdog.cancel()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps(out))
+            print(dumps(out))
         return 0
 
     failed = []
@@ -1251,7 +1271,7 @@ def main():
         if failed:
             out["failed_lines"] = failed
             rc = EXIT_LINE_FAILED
-        print(json.dumps(out), flush=True)
+        print(dumps(out), flush=True)
     if n > 1 and not dry:
         # every rank leaves with the same status
         pass

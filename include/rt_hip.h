@@ -24,9 +24,10 @@
  *     sample, no rt_stats).  These synchronise the stream: rt_trace_work_dev
  *     and rt_photonmap_emit_dev (they return counts), rt_photonmap_build_dev
  *     (once per tree level and wide pass), rt_photonmap_import_dev, rt_render_dev
- *     with rt_stats, and rt_render_dev with recursion (once per depth, to size the
- *     next pass by the number of child rays; a frame is 10-100 ms of device
- *     time by then).  The first call of a size also grows the scene's scratch
+ *     with rt_stats, and rt_render_dev with recursion (once per depth above
+ *     RT_OPT_PATH_DEPTH, to size the next pass by the number of child rays --
+ *     twice per frame by default; the depths below that option run in one
+ *     launch).  The first call of a size also grows the scene's scratch
  *     (hipMalloc; hipFree of the smaller block after a stream synchronise);
  *   - one host thread AND one stream per rt_scene at a time: the scene's
  *     scratch blocks are shared by its calls, so two calls on the same scene
@@ -46,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* error codes */
 #define RT_OK            0
@@ -220,6 +221,15 @@ typedef struct rt_stats {
     int64_t lane_closest_launches, lane_any_launches;
     int64_t lane_closest_rays, lane_any_rays;   /* queue entries traced by those passes (inactive slots included) */
     int64_t lane_closest_work[4], lane_any_work[4];   /* count_work: the part of closest_work / any_work of those passes */
+    /* appended with RT_ABI_VERSION 3 (measurement only): the persistent path kernel (RT_OPT_PATH_DEPTH), which traces the
+     * closest-hit AND the shadow rays of every recursion depth >= that option in one launch.  Its time is NOT part of
+     * trace_closest_ms / trace_any_ms / lane_*; its rays ARE part of rays_reflect / rays_refract / rays_shadow, and its
+     * work part of closest_work / any_work.                                                                        */
+    double  path_ms;            /* device time of that launch (HIP events)                                         */
+    int64_t path_launches;      /* 0 or 1 per chunk of the frame                                                    */
+    int64_t path_roots;         /* queue entries it started from                                                    */
+    int64_t path_closest_rays, path_shadow_rays;   /* rays it traced                                               */
+    int64_t path_work[4];       /* count_work: box tests, triangle records of its closest-hit walks; the same of its shadow walks */
 } rt_stats;
 
 /* 40-byte photon record, field order of PhotonStruct photon.h:133-141.          */
@@ -289,6 +299,14 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
  * 0 = every kernel on the caller's stream (also what rt_stats' per-kernel times should be read from: kernels that share
  * the chip time each other).  RT_RENDER_OVERLAP=0|1.                                                                     */
 #define RT_OPT_RENDER_OVERLAP 7
+/* RT_OPT_PATH_DEPTH (default 2; no counterpart: the reference recurses): with RT_TRAVERSAL_FAST or _BVH, rt_render hands the
+ * rays of recursion depth >= value to ONE persistent kernel in which a lane follows a ray's whole subtree of the
+ * recursion -- closest hit, shadow rays, shading, reflected and refracted children, depth first -- instead of one
+ * pass of kernels per depth with a host round trip between them.  Same hits, same shadow bits, same
+ * children; a pixel's contributions are added subtree by subtree instead of depth by depth (float round-off).  The frame
+ * stays byte-identical under tiling and chunking.  A value above max_depth, or 0, keeps the per-depth passes.
+ * RT_PATH_DEPTH sets the default of new scenes.                                                                      */
+#define RT_OPT_PATH_DEPTH 8
 /* Algorithm of the radiance estimate (rt_photon_irradiance*, the photon renderer) and of rt_photon_knn_set:
  *   RT_KNN_STRICT  LocatePhoton's array / heap code statement by statement, one query per lane: np.index in the
  *                  reference's order, irradiance summed in that order (bit-identical to the reference).

@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_PRIM_TRIANGLE, RT_PRIM_SPHERE, RT_PRIM_DISABLED = 0, 1, 255
 RT_LIGHT_POINT, RT_LIGHT_RECT = 0, 1
 RT_SCENE_CULLING, RT_SCENE_KD_REFERENCE = 1, 2
@@ -23,6 +23,7 @@ RT_OPT_KNN_STATS = 4
 RT_OPT_FUSED_PRIMARY = 5
 RT_OPT_RAY_SORT = 6
 RT_OPT_RENDER_OVERLAP = 7
+RT_OPT_PATH_DEPTH = 8
 RT_NOALLOC_MAX_QUERIES = 262144
 RT_E_INVALID, RT_E_NODEVICE, RT_E_NOMEM, RT_E_LIMIT, RT_E_STATE, RT_E_HIP = -1, -2, -3, -4, -5, -6
 
@@ -80,7 +81,9 @@ class rt_stats(C.Structure):
                 ("closest_work", _i64 * 4), ("any_work", _i64 * 4),
                 ("knn_ms", C.c_double), ("knn_launches", _i64), ("lane_closest_ms", C.c_double), ("lane_any_ms", C.c_double),
                 ("lane_closest_launches", _i64), ("lane_any_launches", _i64), ("lane_closest_rays", _i64),
-                ("lane_any_rays", _i64), ("lane_closest_work", _i64 * 4), ("lane_any_work", _i64 * 4)]
+                ("lane_any_rays", _i64), ("lane_closest_work", _i64 * 4), ("lane_any_work", _i64 * 4),
+                ("path_ms", C.c_double), ("path_launches", _i64), ("path_roots", _i64), ("path_closest_rays", _i64),
+                ("path_shadow_rays", _i64), ("path_work", _i64 * 4)]
 
 
 # numpy views of the POD records

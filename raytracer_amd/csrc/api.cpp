@@ -270,6 +270,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         s->fast = (strcmp(e, "strict") == 0) ? 0 : (strcmp(e, "fast") == 0) ? 1 : (strcmp(e, "lane") == 0) ? 2 : (strcmp(e, "bvh") == 0) ? 3 : s->fast;
     if (const char* e = getenv("RT_FUSED_PRIMARY")) s->fused_primary = atoi(e) != 0;
     if (const char* e = getenv("RT_LANE_DEPTH")) s->lane_depth = atoi(e) < 0 ? 0 : atoi(e);
+    if (const char* e = getenv("RT_PATH_DEPTH")) s->path_depth = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("RT_RAY_SORT")) s->ray_sort = atoi(e) != 0;
     if (const char* e = getenv("RT_RENDER_OVERLAP")) s->overlap_shadow = atoi(e) != 0;
     if (const char* e = getenv("RT_KNN")) s->knn_fast = (strcmp(e, "strict") == 0) ? 0 : 1;
@@ -311,6 +312,7 @@ int rt_scene_set_option(rt_scene* s, int option, int value) {
     if (!s) return rt_fail(RT_E_INVALID, "rt_scene_set_option: NULL scene");
     if (option == RT_OPT_TRAVERSAL && (value == RT_TRAVERSAL_STRICT || value == RT_TRAVERSAL_FAST || value == RT_TRAVERSAL_LANE || value == RT_TRAVERSAL_BVH)) { s->fast = value; return RT_OK; }
     if (option == RT_OPT_LANE_DEPTH && value >= 0) { s->lane_depth = value; return RT_OK; }
+    if (option == RT_OPT_PATH_DEPTH && value >= 0) { s->path_depth = value; return RT_OK; }
     if (option == RT_OPT_FUSED_PRIMARY && (value == 0 || value == 1)) { s->fused_primary = value; return RT_OK; }
     if (option == RT_OPT_RAY_SORT && (value == 0 || value == 1)) { s->ray_sort = value; return RT_OK; }
     if (option == RT_OPT_RENDER_OVERLAP && (value == 0 || value == 1)) { s->overlap_shadow = value; return RT_OK; }

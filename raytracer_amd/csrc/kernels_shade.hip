@@ -83,13 +83,8 @@ k_shade_flags(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __
             f1 = (double)m.refract > 0.0001;                  // hw4.cpp:907 (double literal)
         }
         for (int l = 0; l < L; ++l) {
-            const DevLight lt = sc.lights[l];
-            float lx = lt.pos[0], ly = lt.pos[1], lz = lt.pos[2];
-            if (light_radius > 0.f && code) {                  // soft shadow: one point of the light ball
-                float b3[3];
-                rt_ball(seed, ((uint64_t)px << 16) | (code[i] >> 16), code[i] & 0xffffu, 16 + 8 * l, b3);
-                lx = lx + light_radius * b3[0]; ly = ly + light_radius * b3[1]; lz = lz + light_radius * b3[2];
-            }
+            float lx, ly, lz;
+            light_point(sc, l, code != nullptr, light_radius, seed, px, code ? code[i] : 0u, lx, ly, lz);
             shadow_ray(sc, c, lx, ly, lz, reinterpret_cast<float*>(srays + (i * L + l)));
             sactive[i * L + l] = 0;
         }
@@ -250,34 +245,17 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         const float w = weight ? weight[i] : 1.0f;
         float* o = reinterpret_cast<float*>(orays + pos);
         if ((slot & 1) == 0) {
-            const float dot = c.dx * c.nx + c.dy * c.ny + c.dz * c.nz;
-            const float k2 = 2 * dot;                                  // reflected = dir - 2*dot*normal
-            o[0] = c.hx; o[1] = c.hy; o[2] = c.hz;
-            float rx = c.dx - k2 * c.nx, ry = c.dy - k2 * c.ny, rz = c.dz - k2 * c.nz;
-            if (glossy > 0.f && code) {                        // glossy lobe
-                float b3[3];
-                rt_ball(seed, ((uint64_t)pix[i] << 16) | (code[i] >> 16), code[i] & 0xffffu, 8, b3);
-                rx = rx + glossy * b3[0]; ry = ry + glossy * b3[1]; rz = rz + glossy * b3[2];
-                normalize3(rx, ry, rz);
-            }
-            o[3] = rx; o[4] = ry; o[5] = rz;
+            reflect_child(c, glossy, code != nullptr, seed, pix[i], code ? code[i] : 0u, o);
             oweight[pos] = w * m.reflect; onr[pos] = nr_in ? nr_in[i] : 1.0f;
             ++nrefl;
         } else {
             const float n1 = nr_in ? nr_in[i] : 1.0f, n2 = m.Nr;
-            const float cos1 = c.dx * c.nx + c.dy * c.ny + c.dz * c.nz;
-            const float ratio = n1 / n2;
-            const float sin2 = ratio * sqrt_rn(1 - (cos1 * cos1));
-            const float kk = cos1 * ratio - sqrt_rn(1 - (sin2 * sin2));
-            float tx = ratio * c.dx + kk * c.nx, ty = ratio * c.dy + kk * c.ny, tz = ratio * c.dz + kk * c.nz;
-            normalize3(tx, ty, tz);
-            o[0] = c.hx - sc.refract_bias * c.nx; o[1] = c.hy - sc.refract_bias * c.ny; o[2] = c.hz - sc.refract_bias * c.nz;
-            o[3] = tx; o[4] = ty; o[5] = tz;
+            refract_child(sc, c, n1, n2, o);
             oweight[pos] = w * m.refract; onr[pos] = n2;
             ++nrefr;
         }
         opix[pos] = pix[i];
-        if (ocode) ocode[pos] = (code[i] & 0xffff0000u) | ((2u * (code[i] & 0xffffu) + (unsigned)(slot & 1)) & 0xffffu);
+        if (ocode) ocode[pos] = child_code(code[i], (unsigned)(slot & 1));
         ++pos;
     }
     if (nrefl) atomicAdd(&kinds[0], (unsigned)nrefl);

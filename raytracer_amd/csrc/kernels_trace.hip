@@ -429,11 +429,12 @@ static inline int bvh_lanes_usable(const DevSceneView& sc) {
 }
 // waves of a refilling kernel: enough to fill the chip several times over, never more than the rays need
 // the launch's own claim counter: the next word of the scene's ring, zeroed on the launch's stream
-static inline hipError_t next_ray_counter(DevSceneView& sc, hipStream_t st) {
+hipError_t rtk_next_ray_counter(DevSceneView& sc, hipStream_t st) {
     static std::atomic<unsigned> seq{0};
     sc.ray_counter = sc.ray_counter + 8 * (size_t)(seq.fetch_add(1) % RT_RAY_COUNTERS);
     return hipMemsetAsync(sc.ray_counter, 0, 8 * sizeof(unsigned long long), st);       // the eight range counters of bvh_lanes
 }
+static inline hipError_t next_ray_counter(DevSceneView& sc, hipStream_t st) { return rtk_next_ray_counter(sc, st); }
 // waves of a refilling kernel: never more than the rays need.  Fewer resident walks than the chip can hold are faster --
 // every walk in flight is a stream of scattered line requests and a share of L2 (1 M-triangle mesh, 1080p x 64 spp:
 // 8 192 waves 116.2 ms per frame, 4 096 waves 113.0); a frame that runs two such kernels side by side (render.cpp) asks

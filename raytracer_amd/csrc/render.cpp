@@ -15,9 +15,10 @@ namespace {
 enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
     S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE, S_ORDER_C, S_ORDER_A,
-    S_HITS1, S_SRAYS1, S_SACTIVE1, S_HITS2, S_SRAYS2, S_SACTIVE2, S_QC_RAYS, S_QC_PIX, S_QC_W, S_QC_NR, S_QC_CODE
+    S_HITS1, S_SRAYS1, S_SACTIVE1, S_HITS2, S_SRAYS2, S_SACTIVE2, S_QC_RAYS, S_QC_PIX, S_QC_W, S_QC_NR, S_QC_CODE,
+    S_PATH_CONTRIB, S_PATH_STACK
 };
-static_assert(S_QC_CODE < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_PATH_STACK < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -103,17 +104,19 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     uint32_t* d_total = (uint32_t*)(d_ctr + 8);
     HIPCHK(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long) + 16, st), "memset counters");
 
-    unsigned long long* d_work = nullptr;       // count_work: [0..3] closest, [4..7] any of the wave-synchronous passes, [8..15] the same of the per-lane passes
+    unsigned long long* d_work = nullptr;       // count_work: [0..3] closest, [4..7] any of the wave-synchronous passes, [8..15] the same of the
+                                                // per-lane passes, [16..23] the path kernel (box, tri of its closest walks; [20], [21] of its shadow walks)
     if (stats && p->count_work) {
-        void* w; RTCHK(s->scratch(S_WORK, 16 * sizeof(unsigned long long), &w));
-        HIPCHK(hipMemsetAsync(w, 0, 16 * sizeof(unsigned long long), st), "memset work counters");
+        void* w; RTCHK(s->scratch(S_WORK, 24 * sizeof(unsigned long long), &w));
+        HIPCHK(hipMemsetAsync(w, 0, 24 * sizeof(unsigned long long), st), "memset work counters");
         d_work = (unsigned long long*)w;
     }
 
     EventBag bag;                     // every event of this call; destroyed on every return path
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;      // per-kernel event pairs: [closest begin, closest end, any begin, any end] per pass
-    std::vector<char> pass_lane;      // per pass: traced by the per-lane kernels
+    std::vector<char> pass_lane;      // per pass: 1 = traced by the per-lane kernels, 2 = the path kernel (every depth from here on)
+    int64_t path_roots = 0;
     auto mark = [&](hipStream_t on) -> int {
         if (!stats) return RT_OK;
         hipError_t err; hipEvent_t e = bag.mark(on, &err);
@@ -193,7 +196,35 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     static const int Q_RAYS[3] = {S_QA_RAYS, S_QB_RAYS, S_QC_RAYS}, Q_PIX[3] = {S_QA_PIX, S_QB_PIX, S_QC_PIX}, Q_W[3] = {S_QA_W, S_QB_W, S_QC_W},
                      Q_NR[3] = {S_QA_NR, S_QB_NR, S_QC_NR}, Q_CODE[3] = {S_QA_CODE, S_QB_CODE, S_QC_CODE};
     hipEvent_t order_done = nullptr;                    // the second stream has ordered its shadow rays (rtk_ray_order)
+    // The rays of depth >= RT_OPT_PATH_DEPTH with everything below them: one persistent kernel (kernels_paths.hip) instead of a
+    // pass of kernels and a host round trip per depth.  Needs the build's hierarchy and a queue made by k_spawn (depth >= 1).
+    const bool use_paths = (s->fast == 1 || s->fast == 3) && s->view.nbvh > 0 && s->view.ray_counter != nullptr && s->path_depth >= 1 &&
+                           s->path_depth <= p->max_depth && !p->primary_only && !s->ray_sort && L <= rtk_paths_max_lights();
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
+        if (use_paths && depth >= s->path_depth) {
+            void *pc, *stk;
+            RTCHK(s->scratch(S_PATH_CONTRIB, (size_t)n * 12, &pc));
+            RTCHK(s->scratch(S_PATH_STACK, rtk_paths_stack_bytes(n, depth, p->max_depth), &stk));
+            ++passes; pass_n.push_back(n); pass_lane.push_back(2); path_roots += n;
+            if (order_done) { HIPCHK(hipStreamWaitEvent(st, order_done, 0), "hipStreamWaitEvent"); order_done = nullptr; }
+            RTCHK(mark(st));
+            HIPCHK(rtk_paths(view, q_rays, q_pix, q_w, q_nr, q_code, n, depth, p->max_depth, s->eps_f, p->ambient_intensity, cam->center,
+                             p->start_nr, p->seed, p->light_radius, p->glossy, (float*)pc, stk, d_ctr, d_work ? d_work + 16 : nullptr, st),
+                   "k_paths_bvh_lanes");
+            RTCHK(mark(st)); RTCHK(mark(st)); RTCHK(mark(st));
+            // the entries' sums join the pixels after every earlier pass's (the accumulation stream keeps pass order)
+            if (overlap) {
+                hipError_t err; hipEvent_t e = bag.mark(st, &err);
+                if (!e) return rt_hipfail(err, "event");
+                HIPCHK(hipStreamWaitEvent(sb, e, 0), "hipStreamWaitEvent");
+            }
+            HIPCHK(rtk_accumulate(q_pix, (const float*)pc, n, (float*)accum, sb), "k_accumulate");
+            if (overlap) {
+                hipError_t err; b_last = bag.mark(sb, &err);
+                if (!b_last) return rt_hipfail(err, "event");
+            }
+            break;
+        }
         const int pass_mode = ((s->fast == 1 || s->fast == 3) && depth >= s->lane_depth) ? 2 : s->fast;   // RT_OPT_LANE_DEPTH
         ++passes; pass_n.push_back(n); pass_lane.push_back(pass_mode == 2 ? 1 : 0);
         const bool spawn = !p->primary_only && depth < p->max_depth;
@@ -310,7 +341,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     }   // chunks
     if (stats) {
         { hipError_t err; ev1 = bag.mark(st, &err); if (!ev1) return rt_hipfail(err, "event"); }
-        unsigned long long h[8], hw[16] = {};
+        unsigned long long h[8], hw[24] = {};
         HIPCHK(hipMemcpyAsync(h, d_ctr, sizeof h, hipMemcpyDeviceToHost, st), "read counters");
         if (d_work) HIPCHK(hipMemcpyAsync(hw, d_work, sizeof hw, hipMemcpyDeviceToHost, st), "read work counters");
         HIPCHK(hipStreamSynchronize(st), "sync");
@@ -323,17 +354,25 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         stats->passes = passes;
         stats->kernel_ms = ms;
         for (int c = 0; c < 4; ++c) {
-            stats->closest_work[c] = (int64_t)(hw[c] + hw[8 + c]); stats->any_work[c] = (int64_t)(hw[4 + c] + hw[12 + c]);
+            stats->closest_work[c] = (int64_t)(hw[c] + hw[8 + c] + hw[16 + c]); stats->any_work[c] = (int64_t)(hw[4 + c] + hw[12 + c] + hw[20 + c]);
             stats->lane_closest_work[c] = (int64_t)hw[8 + c]; stats->lane_any_work[c] = (int64_t)hw[12 + c];
         }
+        stats->path_work[0] = (int64_t)hw[16]; stats->path_work[1] = (int64_t)hw[17]; stats->path_work[2] = (int64_t)hw[20]; stats->path_work[3] = (int64_t)hw[21];
+        stats->path_roots = path_roots; stats->path_closest_rays = (int64_t)h[5]; stats->path_shadow_rays = (int64_t)h[6];
         for (size_t i = 0; i + 3 < kev.size(); i += 4) {
             float a = 0.f, b = 0.f;
             HIPCHK(hipEventElapsedTime(&a, kev[i], kev[i + 1]), "event time");
             HIPCHK(hipEventElapsedTime(&b, kev[i + 2], kev[i + 3]), "event time");
+            if (pass_lane[i / 4] == 2) {               // the path kernel: closest and shadow walks of every depth from here on in one launch
+                stats->path_ms += a; stats->path_launches += 1;
+                if (getenv("RT_TRACE_PASSES"))
+                    fprintf(stderr, "pass %zu: %lld queue entries and their subtrees, path kernel %.3f ms\n", i / 4, (long long)pass_n[i / 4], a);
+                continue;
+            }
             const bool any_launched = L > 0 && !fused;
             stats->trace_closest_ms += a; stats->trace_any_ms += b;
             stats->trace_closest_launches += 1; stats->trace_any_launches += any_launched ? 1 : 0;
-            if (pass_lane[i / 4]) {
+            if (pass_lane[i / 4] == 1) {
                 stats->lane_closest_ms += a; stats->lane_closest_launches += 1; stats->lane_closest_rays += pass_n[i / 4];
                 if (any_launched) { stats->lane_any_ms += b; stats->lane_any_launches += 1; stats->lane_any_rays += pass_n[i / 4] * L; }
             }

@@ -231,6 +231,17 @@ hipError_t rtk_generate_drt(const rt_camera& cam, const int32_t* d_tiles, int64_
 hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int64_t ntiles, float ox, float oy,
                               rt_ray* d_rays, int32_t* d_pix, hipStream_t st);
 
+// kernels_trace.hip: the next word group of the scene's ring of claim counters, zeroed on `st` (one ring for every
+// refilling kernel of the library, so two launches in flight never claim from the same words)
+hipError_t rtk_next_ray_counter(DevSceneView& sc, hipStream_t st);
+// kernels_paths.hip: the rays of a queue with their whole subtrees of the recursion, one weighted sum per queue entry
+int rtk_paths_max_lights();
+size_t rtk_paths_stack_bytes(int64_t n, int depth0, int max_depth);
+hipError_t rtk_paths(const DevSceneView& sc, const rt_ray* rays, const int32_t* pix, const float* w, const float* nr,
+                     const uint32_t* code, int64_t n, int depth0, int max_depth, float eps_f, float ambient, const float eye[3],
+                     float start_nr, uint64_t seed, float light_radius, float glossy, float* contrib, void* stack,
+                     unsigned long long* counters, unsigned long long* work, hipStream_t st);
+
 // kernels_shade.hip
 hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
                            int spawn_children, int primary_pass, uint8_t* child_flags, rt_ray* srays, int32_t* sactive,

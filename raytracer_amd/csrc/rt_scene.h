@@ -3,7 +3,7 @@
 #include "rt_internal.h"
 #include <hip/hip_runtime_api.h>
 
-#define RT_NSCRATCH 48
+#define RT_NSCRATCH 56
 
 struct DeviceGuard {
     int prev, cur = -1; bool ok;
@@ -28,6 +28,8 @@ struct rt_scene {
     int knn_fast = 1;                 // radiance estimate: 1 = wave-shared kernel (default), 0 = strict list replay
     int fused_primary = 1;            // rt_render with primary_only: one kernel for the whole frame (RT_OPT_FUSED_PRIMARY)
     int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
+    int path_depth = 2;               // rt_render: rays of this depth and deeper are traced as whole subtrees of the recursion by ONE
+                                      // persistent kernel (kernels_paths.hip, RT_OPT_PATH_DEPTH); a value above max_depth: never
     int ray_sort = 0;                 // rt_render: per-lane passes hand rays to lanes in (cell, octant, Morton) order (RT_OPT_RAY_SORT;
                                       // measured slower on BASELINE configuration 3, DESIGN 4.1c, so off by default)
     int overlap_shadow = 1;           // rt_render: the shadow half of a pass on a second stream beside the next pass (RT_RENDER_OVERLAP=0: off)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "rt_internal.h"
 #include "trace_device.h"
+#include "rng_device.h"
 
 namespace {
 
@@ -51,6 +52,54 @@ __device__ __forceinline__ void shadow_ray(const DevSceneView& sc, const HitCtx&
     float dx = lx - bx, dy = ly - by, dz = lz - bz;
     normalize3(dx, dy, dz);
     o6[0] = bx; o6[1] = by; o6[2] = bz; o6[3] = dx; o6[4] = dy; o6[5] = dz;
+}
+
+// The point of light l a shadow ray aims at: the light's position, or -- soft shadows of the distributed ray tracer
+// (build-defined) -- one uniform point of the ball of radius light_radius around it, drawn from the ray's
+// stream (key = pixel << 16 | sample, position in the recursion, dimension 16 + 8 l)
+__device__ __forceinline__ void light_point(const DevSceneView& sc, int l, bool drt, float light_radius, uint64_t seed, int px,
+                                            uint32_t code, float& lx, float& ly, float& lz) {
+    const DevLight lt = sc.lights[l];
+    lx = lt.pos[0]; ly = lt.pos[1]; lz = lt.pos[2];
+    if (light_radius > 0.f && drt) {
+        float b3[3];
+        rt_ball(seed, ((uint64_t)px << 16) | (code >> 16), code & 0xffffu, 16 + 8 * l, b3);
+        lx = lx + light_radius * b3[0]; ly = ly + light_radius * b3[1]; lz = lz + light_radius * b3[2];
+    }
+}
+
+// The reflected ray of a hit, hw4.cpp:897-904: origin = the hit point, direction = dir - 2 (dir . n) n; with the glossy lobe
+// of the distributed ray tracer the direction + glossy * (a uniform point of the unit ball), normalised
+__device__ __forceinline__ void reflect_child(const HitCtx& c, float glossy, bool drt, uint64_t seed, int px, uint32_t code, float* o6) {
+    const float dot = c.dx * c.nx + c.dy * c.ny + c.dz * c.nz;
+    const float k2 = 2 * dot;                                  // reflected = dir - 2*dot*normal
+    o6[0] = c.hx; o6[1] = c.hy; o6[2] = c.hz;
+    float rx = c.dx - k2 * c.nx, ry = c.dy - k2 * c.ny, rz = c.dz - k2 * c.nz;
+    if (glossy > 0.f && drt) {
+        float b3[3];
+        rt_ball(seed, ((uint64_t)px << 16) | (code >> 16), code & 0xffffu, 8, b3);
+        rx = rx + glossy * b3[0]; ry = ry + glossy * b3[1]; rz = rz + glossy * b3[2];
+        normalize3(rx, ry, rz);
+    }
+    o6[3] = rx; o6[4] = ry; o6[5] = rz;
+}
+
+// The refracted ray of a hit, hw4.cpp:907-924: Snell with n1 (the ray's current index) -> n2 (the material's), origin
+// displaced by refract_bias against the normal
+__device__ __forceinline__ void refract_child(const DevSceneView& sc, const HitCtx& c, float n1, float n2, float* o6) {
+    const float cos1 = c.dx * c.nx + c.dy * c.ny + c.dz * c.nz;
+    const float ratio = n1 / n2;
+    const float sin2 = ratio * sqrt_rn(1 - (cos1 * cos1));
+    const float kk = cos1 * ratio - sqrt_rn(1 - (sin2 * sin2));
+    float tx = ratio * c.dx + kk * c.nx, ty = ratio * c.dy + kk * c.ny, tz = ratio * c.dz + kk * c.nz;
+    normalize3(tx, ty, tz);
+    o6[0] = c.hx - sc.refract_bias * c.nx; o6[1] = c.hy - sc.refract_bias * c.ny; o6[2] = c.hz - sc.refract_bias * c.nz;
+    o6[3] = tx; o6[4] = ty; o6[5] = tz;
+}
+
+// position of a child in the recursion tree (rng_device.h: reflect 2c, refract 2c + 1), sample index kept in the top half
+__device__ __forceinline__ uint32_t child_code(uint32_t code, unsigned slot) {
+    return (code & 0xffff0000u) | ((2u * (code & 0xffffu) + slot) & 0xffffu);
 }
 
 // ambient + per-light Blinn-Phong, hw4.cpp:926-948, including the reference's quirk that `diffuse` / `specular` keep

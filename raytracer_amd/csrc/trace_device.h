@@ -720,15 +720,17 @@ __device__ __forceinline__ void bvh_lane_start(const DevSceneView& sc, const Ray
     wk.r = r; wk.nodes = nodes; wk.i = 0; wk.far_limit = far_limit;
     wk.bc = bvh_consts(sc, r, aux, sc.bvh_root_rho, oct & sc.lane_layout_mask);
 }
-// advances the lane (if `on`) to its next leaf; returns its triangle range
-template <bool ANY>
-__device__ __forceinline__ void bvh_lane_next_leaf(const DevSceneView& sc, BvhLaneWalk& wk, bool on, const Closest& best, int& t0, int& t1) {
+// advances the lane (if `on`) to its next leaf; returns its triangle range.  `limit`: the distance beyond which a box is
+// of no interest (closest hit: the best len so far; any hit: the far limit); nbox (optional): counts the box tests
+__device__ __forceinline__ void bvh_lane_next_leaf_lim(const DevSceneView& sc, BvhLaneWalk& wk, bool on, float limit, int& t0, int& t1,
+                                                       unsigned* nbox = nullptr) {
     t0 = t1 = 0;
     const int nn = sc.nbvh;
     while (on && t0 == t1 && wk.i < nn) {
         const DevBvhNode nd = wk.nodes[wk.i];
         const bool leaf = (nd.meta & 0x100) != 0;
-        const bool hit = bvh_box_hit<false>(nd, wk.r, wk.bc, ANY ? wk.far_limit : best.len);
+        const bool hit = bvh_box_hit<false>(nd, wk.r, wk.bc, limit);
+        if (nbox) *nbox += 1;
         if (!hit) wk.i = leaf ? wk.i + 1 : nd.skip;
         else {
             wk.i = wk.i + 1;
@@ -736,9 +738,13 @@ __device__ __forceinline__ void bvh_lane_next_leaf(const DevSceneView& sc, BvhLa
         }
     }
 }
-// the same step over the compact nodes (rt_internal.h: DevBvhNode32; needs sc.bvh_c32): two 16-byte loads per node
 template <bool ANY>
-__device__ __forceinline__ void bvh_lane_next_leaf_c32(const DevSceneView& sc, BvhLaneWalk& wk, bool on, const Closest& best, int& t0, int& t1) {
+__device__ __forceinline__ void bvh_lane_next_leaf(const DevSceneView& sc, BvhLaneWalk& wk, bool on, const Closest& best, int& t0, int& t1) {
+    bvh_lane_next_leaf_lim(sc, wk, on, ANY ? wk.far_limit : best.len, t0, t1);
+}
+// the same step over the compact nodes (rt_internal.h: DevBvhNode32; needs sc.bvh_c32): two 16-byte loads per node
+__device__ __forceinline__ void bvh_lane_next_leaf_c32_lim(const DevSceneView& sc, BvhLaneWalk& wk, bool on, float limit, int& t0, int& t1,
+                                                           unsigned* nbox = nullptr) {
     t0 = t1 = 0;
     const int nn = sc.nbvh;
     const BvhConsts& b = wk.bc;
@@ -756,8 +762,9 @@ __device__ __forceinline__ void bvh_lane_next_leaf_c32(const DevSceneView& sc, B
         z.x = __builtin_fmaf(z.x, b.rz, b.pz); z.y = __builtin_fmaf(z.y, b.rz, b.pz);
         const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
         const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
-        const bool hit = !(ex < en || ex < 0.0f || en * b.dlen > (ANY ? wk.far_limit : best.len));
+        const bool hit = !(ex < en || ex < 0.0f || en * b.dlen > limit);
         const bool leaf = (link >> 31) != 0;
+        if (nbox) *nbox += 1;
         if (!hit) wk.i = leaf ? wk.i + 1 : (int)link;
         else {
             wk.i = wk.i + 1;
@@ -765,13 +772,20 @@ __device__ __forceinline__ void bvh_lane_next_leaf_c32(const DevSceneView& sc, B
         }
     }
 }
-// the triangles [t0, t1) of the lane's leaf; any-hit: returns true (and ends the walk) when one occludes
 template <bool ANY>
-__device__ __forceinline__ bool bvh_lane_leaf(const DevSceneView& sc, BvhLaneWalk& wk, int t0, int t1, float eps_f, bool use_tmax, Closest& best) {
+__device__ __forceinline__ void bvh_lane_next_leaf_c32(const DevSceneView& sc, BvhLaneWalk& wk, bool on, const Closest& best, int& t0, int& t1) {
+    bvh_lane_next_leaf_c32_lim(sc, wk, on, ANY ? wk.far_limit : best.len, t0, t1);
+}
+// the triangles [t0, t1) of the lane's leaf; any-hit: returns true (and ends the walk) when one occludes
+// (`any` is a compile-time constant in bvh_lane_leaf<ANY>, the lane's mode in the path kernel of kernels_paths.hip;
+// ntri (optional): counts the triangle records read)
+__device__ __forceinline__ bool bvh_lane_leaf_any(const DevSceneView& sc, BvhLaneWalk& wk, int t0, int t1, float eps_f, bool use_tmax,
+                                                  const bool ANY, Closest& best, unsigned* ntri = nullptr) {
     const Rayf& r = wk.r;
     for (int ti = t0; ti < t1; ++ti) {
         const DevLeafTri* __restrict__ t = sc.bvh_tris + ti;
         if (ANY && use_tmax && (t->flags & RT_PF_SKIP_SHADOW)) continue;
+        if (ntri) *ntri += 1;
         const float e1x = t->e1[0], e1y = t->e1[1], e1z = t->e1[2];
         const float e2x = t->e2[0], e2y = t->e2[1], e2z = t->e2[2];
         const float pvx = r.dy * e2z - r.dz * e2y;
@@ -811,6 +825,10 @@ __device__ __forceinline__ bool bvh_lane_leaf(const DevSceneView& sc, BvhLaneWal
         }
     }
     return false;
+}
+template <bool ANY>
+__device__ __forceinline__ bool bvh_lane_leaf(const DevSceneView& sc, BvhLaneWalk& wk, int t0, int t1, float eps_f, bool use_tmax, Closest& best) {
+    return bvh_lane_leaf_any(sc, wk, t0, t1, eps_f, use_tmax, ANY, best);
 }
 
 // primitives outside every tree, in index order (the whole scene for final.cpp)
