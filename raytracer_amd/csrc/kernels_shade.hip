@@ -216,7 +216,7 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         const uint8_t* __restrict__ flags, int64_t nflags, const uint32_t* __restrict__ block_offsets,
         rt_ray* __restrict__ orays, int32_t* __restrict__ opix, float* __restrict__ oweight, float* __restrict__ onr,
         unsigned long long* __restrict__ counters, const uint32_t* __restrict__ code, uint32_t* __restrict__ ocode,
-        uint64_t seed, float glossy) {
+        uint64_t seed, float glossy, uint8_t* __restrict__ ooct) {
     __shared__ uint32_t wsum[SCAN_BLOCK / 64];
     __shared__ unsigned int kinds[2];
     if (threadIdx.x < 2) kinds[threadIdx.x] = 0;
@@ -255,6 +255,7 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
             ++nrefr;
         }
         opix[pos] = pix[i];
+        if (ooct) ooct[pos] = (uint8_t)((o[3] < 0.f ? 1u : 0u) | (o[4] < 0.f ? 2u : 0u) | (o[5] < 0.f ? 4u : 0u));   // k_ray_keys' octant
         if (ocode) ocode[pos] = child_code(code[i], (unsigned)(slot & 1));
         ++pos;
     }
@@ -262,6 +263,72 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
     if (nrefr) atomicAdd(&kinds[1], (unsigned)nrefr);
     __syncthreads();
     if (threadIdx.x < 2 && kinds[threadIdx.x]) atomicAdd(counters + 3 + threadIdx.x, (unsigned long long)kinds[threadIdx.x]);
+}
+
+// ---- stable partition of a queue by direction octant (the order in which a wave-synchronous pass takes its rays) -------
+// k_spawn leaves one octant byte per child; the order is made from those bytes alone -- count per tile and octant, one
+// scan over (octant-major) tile counts, scatter -- 50 MB read twice and 200 MB written for 49.5 M rays, where keys +
+// radix sort of (key, index) pairs moved 3 GB and took 10 ms beside the shadow kernel (profiles/r02_timeline_drt_1m.txt).
+// Packed counters: four 16-bit fields per 64-bit word (a tile has 2 048 entries), octants 0-3 in `a`, 4-7 in `b`.
+__device__ __forceinline__ void oct_tile_counts(const uint8_t* __restrict__ oct, int64_t n, int64_t base, uint8_t o8[SCAN_ITEMS],
+                                                unsigned long long& a, unsigned long long& b) {
+    a = 0ull; b = 0ull;
+    unsigned long long v = 0x0808080808080808ull;                  // 8 = no entry
+    if (base + SCAN_ITEMS <= n) v = *reinterpret_cast<const unsigned long long*>(oct + base);
+    else for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) v = (v & ~(0xffull << (8 * k))) | ((unsigned long long)oct[base + k] << (8 * k));
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const unsigned o = (unsigned)(v >> (8 * k)) & 0xffu;
+        o8[k] = (uint8_t)o;
+        if (o < 4u) a += 1ull << (16 * o); else if (o < 8u) b += 1ull << (16 * (o - 4u));
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(SCAN_BLOCK)
+k_oct_count(const uint8_t* __restrict__ oct, int64_t n, int64_t nblocks, uint32_t* __restrict__ hist /* [8][nblocks] */) {
+    __shared__ unsigned long long red[2][SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint8_t o8[SCAN_ITEMS]; unsigned long long a, b;
+    oct_tile_counts(oct, n, base, o8, a, b);
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        unsigned long long t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += red[threadIdx.x >> 2][w];
+        hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = (uint32_t)(t >> (16 * (threadIdx.x & 3))) & 0xffffu;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(SCAN_BLOCK)
+k_oct_scatter(const uint8_t* __restrict__ oct, int64_t n, int64_t nblocks, const uint32_t* __restrict__ offs /* scanned hist */,
+              int32_t* __restrict__ order) {
+    __shared__ unsigned long long wsum[2][SCAN_BLOCK / 64];
+    __shared__ uint32_t tile_off[8];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    if (threadIdx.x < 8) tile_off[threadIdx.x] = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+    uint8_t o8[SCAN_ITEMS]; unsigned long long a, b;
+    oct_tile_counts(oct, n, base, o8, a, b);
+    // exclusive scan of the packed counts over the block: within the wave, then across the four waves
+    unsigned long long ia = a, ib = b;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long ta = __shfl_up(ia, off), tb = __shfl_up(ib, off);
+        if (lane >= off) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) { wsum[0][threadIdx.x >> 6] = ia; wsum[1][threadIdx.x >> 6] = ib; }
+    __syncthreads();
+    unsigned long long ea = ia - a, eb = ib - b;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) { ea += wsum[0][w]; eb += wsum[1][w]; }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const unsigned o = o8[k];
+        if (o >= 8u) continue;
+        unsigned r;
+        if (o < 4u) { r = (unsigned)(ea >> (16 * o)) & 0xffffu; ea += 1ull << (16 * o); }
+        else { r = (unsigned)(eb >> (16 * (o - 4u))) & 0xffffu; eb += 1ull << (16 * (o - 4u)); }
+        order[tile_off[o] + r] = (int32_t)(base + k);
+    }
 }
 
 // GenerateColorImage's pixel write, hw4.cpp:1108-1122.  One thread per primary ray of this rank.
@@ -351,13 +418,32 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
                                 const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
                                 float* onr, unsigned long long* counters, const uint32_t* code, uint32_t* ocode,
-                                uint64_t seed, float glossy, hipStream_t st) {
+                                uint64_t seed, float glossy, hipStream_t st, uint8_t* ooct) {
     if (nflags <= 0) return hipSuccess;
     const int64_t nb = rtk_scan_blocks_needed(nflags);
     hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, nflags, block_sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, nb, d_total);
     hipLaunchKernelGGL(k_spawn, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, sc, rays, hits, pix, weight, nr_in, flags,
-                       nflags, block_sums, orays, opix, oweight, onr, counters, code, ocode, seed, glossy);
+                       nflags, block_sums, orays, opix, oweight, onr, counters, code, ocode, seed, glossy, ooct);
+    return hipGetLastError();
+}
+
+// order of work for a wave-synchronous pass: the queue's entries by direction octant, queue order kept inside an octant.
+// d_oct: k_spawn's octant bytes; d_work: rtk_octant_order_workspace(n) bytes; *order_out points into it.
+size_t rtk_octant_order_workspace(int64_t n) {
+    const int64_t nb = rtk_scan_blocks_needed(n);
+    return (size_t)n * 4 + 256 + (size_t)(8 * nb + 8) * 4 + 256;
+}
+hipError_t rtk_octant_order(const uint8_t* d_oct, int64_t n, void* d_work, const int32_t** order_out, hipStream_t st) {
+    *order_out = nullptr;
+    if (n < 4096 || n > 0x7fffffff || !d_work || !d_oct) return hipSuccess;
+    const int64_t nb = rtk_scan_blocks_needed(n);
+    int32_t* order = (int32_t*)d_work;
+    uint32_t* hist = (uint32_t*)((char*)d_work + (((size_t)n * 4 + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_oct_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, d_oct, n, nb, hist);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, hist, 8 * nb, hist + 8 * nb);      // octant-major: a stable partition
+    hipLaunchKernelGGL(k_oct_scatter, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, d_oct, n, nb, hist, order);
+    *order_out = order;
     return hipGetLastError();
 }
 

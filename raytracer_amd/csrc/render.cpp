@@ -16,9 +16,9 @@ enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
     S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE, S_ORDER_C, S_ORDER_A,
     S_HITS1, S_SRAYS1, S_SACTIVE1, S_HITS2, S_SRAYS2, S_SACTIVE2, S_QC_RAYS, S_QC_PIX, S_QC_W, S_QC_NR, S_QC_CODE,
-    S_PATH_CONTRIB, S_PATH_STACK
+    S_PATH_CONTRIB, S_PATH_STACK, S_Q_OCT
 };
-static_assert(S_PATH_STACK < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_Q_OCT < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -196,6 +196,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     static const int Q_RAYS[3] = {S_QA_RAYS, S_QB_RAYS, S_QC_RAYS}, Q_PIX[3] = {S_QA_PIX, S_QB_PIX, S_QC_PIX}, Q_W[3] = {S_QA_W, S_QB_W, S_QC_W},
                      Q_NR[3] = {S_QA_NR, S_QB_NR, S_QC_NR}, Q_CODE[3] = {S_QA_CODE, S_QB_CODE, S_QC_CODE};
     hipEvent_t order_done = nullptr;                    // the second stream has ordered its shadow rays (rtk_ray_order)
+    const uint8_t* q_oct = nullptr;                     // the queue's direction octants, one byte per ray (k_spawn), or NULL
+    static const bool oct_partition = [] { const char* e = getenv("RT_OCT_PARTITION"); return e ? atoi(e) != 0 : true; }();
     // The rays of depth >= RT_OPT_PATH_DEPTH with everything below them: one persistent kernel (kernels_paths.hip) instead of a
     // pass of kernels and a host round trip per depth.  Needs the build's hierarchy and a queue made by k_spawn (depth >= 1).
     const bool use_paths = (s->fast == 1 || s->fast == 3) && s->view.nbvh > 0 && s->view.ray_counter != nullptr && s->path_depth >= 1 &&
@@ -254,11 +256,14 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         // (two radix passes over the key's 15 cell bits): any-hit of pass 1 11.7 -> 8.9 ms, frame 90.5 -> 86.8 ms; cell +
         // octant or the full 30-bit key give the same (87.7 / 87.3), the cell order for the closest-hit rays instead of the
         // octants is slower (92.5), and either order for the per-lane passes is slower, again (90.4 - 97.7).  RT_OCT_PARTITION=0: off.
-        static const bool oct_partition = [] { const char* e = getenv("RT_OCT_PARTITION"); return e ? atoi(e) != 0 : true; }();
         const bool by_octant = oct_partition && pass_mode == 3 && depth >= 1 && s->view.nbvh > 0;
         if (sorted) {
             void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
             HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st), "ray order");
+        } else if (by_octant && q_oct) {
+            // a stable partition by octant from the bytes k_spawn left beside the queue: count, scan, scatter
+            void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_octant_order_workspace(n), &ow));
+            HIPCHK(rtk_octant_order(q_oct, n, ow, &order_c, st), "octant order");
         } else if (by_octant) {
             void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
             HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st, RT_ORDER_OCTANT), "ray order");
@@ -324,14 +329,21 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         }
         void* ocode = nullptr;
         if (drt) RTCHK(s->scratch(Q_CODE[qo], (size_t)n * 2 * 4, &ocode));
+        // the next pass, if wave-synchronous, takes its rays by direction octant: k_spawn notes the octants
+        void* ooct = nullptr;
+        {
+            const int next_mode = ((s->fast == 1 || s->fast == 3) && depth + 1 >= s->lane_depth) ? 2 : s->fast;
+            const bool next_paths = use_paths && depth + 1 >= s->path_depth;
+            if (oct_partition && next_mode == 3 && !next_paths && s->view.nbvh > 0 && !sorted) RTCHK(s->scratch(S_Q_OCT, (size_t)n * 2, &ooct));
+        }
         HIPCHK(rtk_compact_children(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, nr_in, (const uint8_t*)flags, 2 * n,
                                     (uint32_t*)bsums, d_total, (rt_ray*)orays, (int32_t*)opix, (float*)ow, (float*)onr,
-                                    d_ctr, q_code, (uint32_t*)ocode, p->seed, p->glossy, st), "compact children");
+                                    d_ctr, q_code, (uint32_t*)ocode, p->seed, p->glossy, st, (uint8_t*)ooct), "compact children");
         uint32_t total = 0;
         HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st), "read child count");
         HIPCHK(hipStreamSynchronize(st), "sync");
         q_rays = (const rt_ray*)orays; q_pix = (const int32_t*)opix; q_w = (const float*)ow; q_nr = (const float*)onr;
-        q_code = (const uint32_t*)ocode;
+        q_code = (const uint32_t*)ocode; q_oct = (const uint8_t*)ooct;
         n = (int64_t)total;
     }
     if (b_last) HIPCHK(hipStreamWaitEvent(st, b_last, 0), "hipStreamWaitEvent");       // the frame needs every pass's sum

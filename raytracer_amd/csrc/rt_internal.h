@@ -257,7 +257,11 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
                                 const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
                                 float* onr, unsigned long long* counters, const uint32_t* code, uint32_t* ocode,
-                                uint64_t seed, float glossy, hipStream_t st);
+                                uint64_t seed, float glossy, hipStream_t st, uint8_t* ooct = nullptr);
+// ooct (optional): one byte per child, the octant of its direction; rtk_octant_order turns them into the order in which a
+// wave-synchronous pass takes the queue (a stable partition by octant)
+size_t rtk_octant_order_workspace(int64_t n);
+hipError_t rtk_octant_order(const uint8_t* d_oct, int64_t n, void* d_work, const int32_t** order_out, hipStream_t st);
 hipError_t rtk_reduce_pairs(const unsigned int* block_pairs, int64_t nblocks, unsigned long long* counters, hipStream_t st);
 // kernels_primary.hip: the primary + shadow frame in one kernel (rt_params.primary_only, fast traversal, <= 32 lights)
 int rtk_primary_only_max_lights();
