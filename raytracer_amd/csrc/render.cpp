@@ -203,7 +203,14 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     const bool use_paths = (s->fast == 1 || s->fast == 3) && s->view.nbvh > 0 && s->view.ray_counter != nullptr && s->path_depth >= 1 &&
                            s->path_depth <= p->max_depth && !p->primary_only && !s->ray_sort && L <= rtk_paths_max_lights();
     for (int depth = 0; depth <= p->max_depth && n > 0; ++depth) {
-        if (use_paths && depth >= s->path_depth) {
+        // ... when the queue is small: the kernel needs 128 registers per lane (4 waves per SIMD), and on a queue that fills the
+        // chip many times over the lean per-depth kernels (6 waves per SIMD, closest and shadow walks on two streams) get more
+        // walks in flight -- 1 M-triangle mesh, 1080p x 64 spp, depth >= 2: 9.3 M entries, passes 40 ms, path kernel 51 ms; one
+        // rank's share of that frame at 8 ranks: 0.97 M entries, passes 10.3 ms, path kernel 9.9 ms and no per-depth round trips
+        // (frame 20.5 -> 16.5 ms).  RT_PATH_MAX_ROOTS overrides the threshold.
+        // The choice is made once, at the option's depth (deeper queues are always smaller).
+        static const int64_t path_max_roots = [] { const char* e = getenv("RT_PATH_MAX_ROOTS"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)3000000; }();
+        if (use_paths && depth == s->path_depth && n <= path_max_roots) {
             void *pc, *stk;
             RTCHK(s->scratch(S_PATH_CONTRIB, (size_t)n * 12, &pc));
             RTCHK(s->scratch(S_PATH_STACK, rtk_paths_stack_bytes(n, depth, p->max_depth), &stk));
@@ -333,7 +340,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         void* ooct = nullptr;
         {
             const int next_mode = ((s->fast == 1 || s->fast == 3) && depth + 1 >= s->lane_depth) ? 2 : s->fast;
-            const bool next_paths = use_paths && depth + 1 >= s->path_depth;
+            const bool next_paths = false;      // (the path kernel takes its queue in queue order; whether it runs is known only with the child count)
             if (oct_partition && next_mode == 3 && !next_paths && s->view.nbvh > 0 && !sorted) RTCHK(s->scratch(S_Q_OCT, (size_t)n * 2, &ooct));
         }
         HIPCHK(rtk_compact_children(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, nr_in, (const uint8_t*)flags, 2 * n,
