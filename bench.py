@@ -723,11 +723,11 @@ def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_
             rres = (8, 8)
             rcam = ol.oracle_camera(sd.eye, sd.view, sd.fov, *rres)
             xs, ys = np.meshgrid(np.arange(rres[0]), np.arange(rres[1]), indexing="ij")
-            rays = ol.oracle_primary_rays(rcam, xs.ravel(), ys.ravel())
-            o3 = np.ascontiguousarray(rays[:, :3]); d3 = np.ascontiguousarray(rays[:, 3:])
-            rrgb = np.zeros((rays.shape[0], 3), np.float32); ha = np.zeros(rays.shape[0], np.uint8)
+            eye = ol.oracle_primary_rays(rcam, xs.ravel(), ys.ravel())
+            o3 = np.ascontiguousarray(eye[:, :3]); d3 = np.ascontiguousarray(eye[:, 3:])
+            rrgb = np.zeros((eye.shape[0], 3), np.float32); ha = np.zeros(eye.shape[0], np.uint8)
             t0 = time.perf_counter()
-            R.reff_eye_trace(o3.ctypes.data, d3.ctypes.data, 0, 2.4, rays.shape[0], rrgb.ctypes.data, ha.ctypes.data)
+            R.reff_eye_trace(o3.ctypes.data, d3.ctypes.data, 0, 2.4, eye.shape[0], rrgb.ctypes.data, ha.ctypes.data)
             ref_s = time.perf_counter() - t0
             R.reff_maps_create(1, 1)
             o2 = ol.OracleScene(sd)

@@ -541,330 +541,6 @@ k_irr_main(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const floa
     }
 }
 
-// ---- the per-lane walk with the list as 16-bit keys ---------------------------------------------------------------------
-// k_irr_main<104, LANE> keeps 104 dist2 bit patterns per lane: 141 registers, three waves per SIMD, and the walk -- one
-// dependent 64-byte line per step, served from L2 -- waits on memory for half of its wave-cycles; the list's insertion
-// chain is most of the vector work.  Here the SELECTION runs on 16-bit keys, key(d2) = the upper half of d2's bit pattern
-// (sign 0, 8 exponent bits, 7 mantissa bits: monotone in d2, 0.8 % wide): two entries per register, 52 registers for
-// 104 entries, five waves per SIMD.  What the keys cannot say is recovered exactly:
-//   phase 2   the k + 1 smallest KEYS among the reachable photons within the radius, by the same walk with the same
-//             pruning; K* = the (k+1)-th smallest key.  A photon with key < K* is among the k nearest whatever its low
-//             bits are; the photons with key == K* (the `bucket`, one or two on average) are undecided;
-//   phase 1   as in k_irr_main (which photon the reference evicts), its early stop tested against the bucket's upper
-//             edge instead of the exact k-th dist2 (a later stop, the same answer);
-//   phase 3   the second walk, radius = the bucket's upper edge: photons below the bucket are members -- counted,
-//             the largest exact dist2 among them noted, their power summed where they face the surface -- and the
-//             bucket's photons go into a small exact list (the 8 smallest dist2 with their indices).  The k-th and
-//             (k+1)-th smallest dist2 are then exact: entries k - below - 1 and k - below of that list (or the largest
-//             dist2 below the bucket), T follows as in k_irr_main, and the bucket's photons within T join the sum.
-// A bucket of more than 8 photons, or any count that does not add up (exact ties), flags the query for the strict
-// kernel, as ties always did.  Same sets, same found, same radius; the sum adds the same photons in another order.
-namespace {
-
-// sorted insertion of a 16-bit key into the ascending packed list: reg[j] = V[2j] | V[2j+1] << 16.  Per register, with the
-// carry c (>= every entry before): new lo = min(lo, c), new hi = min(hi, max(lo, c)), carry out = max(hi, c) -- three
-// packed instructions for two entries: q = pk_max(reg, c c); w = (c, q.lo); reg = pk_min(reg, w); the carry rides in q's
-// upper half (op_sel reads it for both halves of the next pk_max).
-template <int NR>
-__device__ __forceinline__ void w_insert16(unsigned (&reg)[NR], unsigned key) {
-    static_assert(NR % 2 == 0, "pairs of registers");
-    if (__ballot(key < (reg[NR - 1] >> 16)) == 0ull) return;
-    unsigned c = key << 16;                                               // the carry, in the upper half
-    const unsigned sel = 0x05040302u;                                     // v_perm: low half = c's upper half, upper half = q's low half
-#pragma unroll
-    for (int j = 0; j < NR; j += 2) {
-        unsigned q;
-        asm("v_pk_max_u16 %2, %0, %3 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-            "v_perm_b32 %3, %2, %3, %4\n\t"
-            "v_pk_min_u16 %0, %0, %3\n\t"
-            "v_pk_max_u16 %3, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-            "v_perm_b32 %2, %3, %2, %4\n\t"
-            "v_pk_min_u16 %1, %1, %2"
-            : "+v"(reg[j]), "+v"(reg[j + 1]), "=&v"(q), "+v"(c)
-            : "s"(sel));
-    }
-}
-
-}  // namespace
-
-template <int NR>
-__global__ void __launch_bounds__(64)
-k_irr_lane16(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
-             const float* __restrict__ nrm3, int64_t q, int k, float maxDist, float* __restrict__ out_rgb,
-             const float* __restrict__ tables, int32_t* __restrict__ redo_list, unsigned* __restrict__ redo_count,
-             const int32_t* __restrict__ perm, unsigned long long* __restrict__ dbg) {
-    constexpr int KMAX = 2 * NR;
-    constexpr int NBK = 8;                                                // exact list of the undecided bucket
-    const int lane = threadIdx.x;
-    const long long t_begin = dbg ? wall_clock64() : 0;
-    // segments of IRR_SEG consecutive chunks of the sorted queries per XCD label (k_irr_main says why)
-    const unsigned full = (gridDim.x / (8u * IRR_SEG)) * (8u * IRR_SEG), wj = blockIdx.x >> 3;
-    const unsigned chunk = blockIdx.x < full ? ((wj / IRR_SEG) * 8u + (blockIdx.x & 7u)) * IRR_SEG + (wj % IRR_SEG) : blockIdx.x;
-    const int64_t qs = (int64_t)chunk * 64 + lane;
-    const bool valid = qs < q;
-    const int64_t qi = valid ? (perm ? (int64_t)perm[qs] : qs) : 0;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (valid) { qx = pos3[3 * qi]; qy = pos3[3 * qi + 1]; qz = pos3[3 * qi + 2]; }
-    const DevPhotonPos* __restrict__ pp = ph + 2 * (n + 1);
-    const DevPhotonPow* __restrict__ pq = reinterpret_cast<const DevPhotonPow*>(pp + (n + 2));
-    const float4* __restrict__ nodes64 = reinterpret_cast<const float4*>(ph) + rt_photon_nodes64_offset(n);
-    const unsigned un = (unsigned)n, nb = (unsigned)(n / 2);
-    const float r0 = maxDist * maxDist;                                    // np.dist2[0], photon.cpp:405
-    const bool live = valid && n >= 1;
-    bool ambiguous = false;
-    unsigned d_p1 = 0, d_v2 = 0, d_c2 = 0, d_v3 = 0, d_m3 = 0, d_lanes = 0;
-
-    __shared__ float lane_stack[32 * 64];
-    auto boxdist6 = [&](float lx, float ly, float lz, float hx, float hy, float hz) -> float {
-        const float dx = __builtin_fmaxf(__builtin_fmaxf(lx - qx, qx - hx), 0.0f);
-        const float dy = __builtin_fmaxf(__builtin_fmaxf(ly - qy, qy - hy), 0.0f);
-        const float dz = __builtin_fmaxf(__builtin_fmaxf(lz - qz, qz - hz), 0.0f);
-        float d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        return d;
-    };
-    // the walk of k_irr_main<., LANE>: one 64-byte line per step, near child first, the far child's box distance on a
-    // per-lane stack in LDS, the next record chosen and fetched before this node's photons are visited
-    auto lane_walk = [&](bool start, auto&& bound, auto&& visit, unsigned& steps) {
-        unsigned i = start ? 1u : 0u, pending = 0u;
-        const float4* __restrict__ np = nodes64 + 4 * (size_t)i;
-        float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-        while (__ballot(i != 0u) != 0ull) {
-            ++steps;
-            const bool on = i != 0u;
-            const unsigned pk = (unsigned)__float_as_int(q0.w);
-            const float d_own = w_dist2(q0, qx, qy, qz);
-            const unsigned c0 = 2u * i;
-            const bool has_l = on && c0 <= un, has_r = on && c0 + 1u <= un;
-            const float dl = boxdist6(q1.x, q1.y, q1.z, q1.w, q2.x, q2.y), dr = boxdist6(q2.z, q2.w, q3.x, q3.y, q3.z, q3.w);
-            const bool leaf_l = has_l && c0 > nb, leaf_r = has_r && c0 + 1u > nb;
-            unsigned next = 0u;
-            if (on) {
-                const float bd = bound();
-                const bool wl = has_l && !leaf_l && dl <= bd, wr = has_r && !leaf_r && dr <= bd;
-                const int di = 31 - __builtin_clz(i);
-                if (wl && wr) {
-                    const bool left_first = dl <= dr;
-                    lane_stack[(di + 1) * 64 + lane] = left_first ? dr : dl;
-                    pending |= 1u << (di + 1);
-                    next = left_first ? c0 : c0 + 1u;
-                } else if (wl) next = c0;
-                else if (wr) next = c0 + 1u;
-                while (next == 0u && pending != 0u) {
-                    const int d = 31 - __builtin_clz(pending);
-                    pending &= ~(1u << d);
-                    if (lane_stack[d * 64 + lane] <= bd) next = (i >> (di - d)) ^ 1u;
-                }
-            }
-            const float4* __restrict__ nn = nodes64 + 4 * (size_t)next;
-            const float4 n0 = nn[0], n1 = nn[1], n2 = nn[2], n3 = nn[3];
-            visit(d_own, i, pk, true, on);
-            if (dbg) d_lanes += (unsigned)(__popcll(__ballot(on)) + __popcll(__ballot(leaf_l)) + __popcll(__ballot(leaf_r)));
-            if (__ballot(leaf_l) != 0ull) visit(dl, c0, (pk & 8u) ? RT_PH_UNREACHABLE : 0u, false, leaf_l);
-            if (__ballot(leaf_r) != 0ull) visit(dr, c0 + 1u, (pk & 16u) ? RT_PH_UNREACHABLE : 0u, false, leaf_r);
-            i = next; q0 = n0; q1 = n1; q2 = n2; q3 = n3;
-        }
-    };
-    // the largest dist2 with a key <= kk, never beyond the search radius (kk = 0x7f80 is +inf's key)
-    auto key_edge = [&](unsigned kk) -> float {
-        const float e = kk >= 0x7f80u ? r0 : __int_as_float((int)((kk << 16) | 0xffffu));
-        return e < r0 ? e : r0;
-    };
-
-    // ---- phase 2: the k + 1 smallest keys per lane ---------------------------------------------------------------
-    unsigned reg[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {                                        // low sentinels keep the (k+1)-th smallest at the last entry
-        const unsigned lo = (2 * j < KMAX - (k + 1)) ? 0u : 0x7f80u, hi = (2 * j + 1 < KMAX - (k + 1)) ? 0u : 0x7f80u;
-        reg[j] = lo | (hi << 16);
-    }
-    int cnt = 0;
-    float tau = r0;
-    // a first radius per lane (k_irr_main): the largest dist2 in the smallest sub-heap around the query's leaf that holds at
-    // least k + 5 photons
-    if (live) {
-        unsigned leaf = 1;
-        while (2 * leaf <= un) {
-            const float4 rec = *reinterpret_cast<const float4*>(pp + leaf);
-            leaf = 2 * leaf + ((w_delta(rec, qx, qy, qz) > 0.0f && 2 * leaf + 1 <= un) ? 1u : 0u);
-        }
-        unsigned root = leaf, levels = 1, have = 1;
-        while (have < (unsigned)k + 5u && root > 1) {
-            root >>= 1; ++levels;
-            have = 0;
-            for (unsigned j = 0; j < levels; ++j) {
-                const unsigned first = root << j, last = first + (1u << j) - 1u;
-                if (first <= un) have += (last <= un ? last : un) - first + 1u;
-            }
-        }
-        if (have >= (unsigned)k + 5u) {
-            float far = 0.f;
-            for (unsigned j = 0; j < levels; ++j) {
-                const unsigned first = root << j;
-                for (unsigned t = 0; t < (1u << j) && first + t <= un; ++t) {
-                    const float d2 = w_dist2(*reinterpret_cast<const float4*>(pp + first + t), qx, qy, qz);
-                    far = d2 > far ? d2 : far;
-                }
-            }
-            if (far == far) tau = far < tau ? far : tau;
-        }
-    }
-    unsigned ktau = (unsigned)__float_as_int(tau) >> 16;                   // candidates: key <= ktau (tau >= 0 or NaN: NaN finds nothing)
-    if (!(tau == tau)) ktau = 0u;
-    float bd2 = key_edge(ktau);
-    if (__ballot(live) != 0ull) {
-        lane_walk(live, [&]() { return bd2; },
-                  [&](float d2, unsigned, unsigned pk, bool, bool al) {
-                      const unsigned key = (unsigned)__float_as_int(d2) >> 16;
-                      const bool cand = al && d2 < r0 && key <= ktau && !(pk & RT_PH_UNREACHABLE);
-                      if (__ballot(cand) != 0ull) {
-                          ++d_c2;
-                          cnt += cand ? 1 : 0;
-                          w_insert16<NR>(reg, cand ? key : 0x7f80u);
-                          const unsigned last = reg[NR - 1] >> 16;
-                          if (last < ktau) { ktau = last; bd2 = key_edge(ktau); }
-                      }
-                  }, d_v2);
-    }
-    const unsigned kstar = reg[NR - 1] >> 16;                              // the (k+1)-th smallest key (0x7f80: fewer than k + 1 candidates)
-    const bool evict = cnt > k;                                            // |S| >= k+1: the reference's heap exists
-    const float U = key_edge(kstar);                                       // every photon of the k + 1 nearest has dist2 <= U
-
-    // ---- phase 1: which photon the reference evicts (k_irr_main), early stop against U >= the k-th nearest's dist2 ---
-    int E = -1;
-    float dE = -1.f;
-    bool beyond = false;
-    if (live && evict) {
-        const unsigned uhalf = half > 0 ? (unsigned)half : 0u;
-        int acc = 0;
-        float m2 = -1.f;
-        unsigned i = 1, child = 0;
-        bool up = false;
-        for (;;) {
-            const float4 rec = *reinterpret_cast<const float4*>(ph + i);
-            ++d_p1;
-            if (i < uhalf) {
-                const float delta = w_delta(rec, qx, qy, qz);
-                const unsigned near = (delta > 0.0f) ? 2 * i + 1 : 2 * i;
-                if (!up) { i = near; continue; }
-                if (child == near && delta * delta < r0) { i = near ^ 1u; up = false; continue; }
-            }
-            const float d2 = w_dist2(rec, qx, qy, qz);
-            if (d2 < r0) {
-                if (++acc > k) break;
-                if (d2 > U) { beyond = true; break; }                      // beyond the k-th nearest: so is E, and E is no member
-                if (d2 > dE) { m2 = dE; dE = d2; E = (int)i; }
-                else if (d2 > m2) m2 = d2;
-            }
-            if (i == 1) break;
-            child = i; i >>= 1; up = true;
-        }
-        if (beyond) { E = -1; dE = 3.0e38f; }
-        else if (acc <= k || dE == m2) ambiguous = true;
-    }
-    const int found = evict ? k : cnt;
-
-    // ---- phase 3: members below the bucket summed, the bucket listed exactly ----------------------------------------
-    float r = 0.f, g = 0.f, b = 0.f;
-    int n_below = 0, members = 0, n_bucket = 0;
-    float max_below = -1.f;
-    int bk_d[NBK]; unsigned bk_i[NBK];
-#pragma unroll
-    for (int e = 0; e < NBK; ++e) { bk_d[e] = 0x7f800000; bk_i[e] = 0u; }
-    const bool summing = live && !ambiguous && found >= 8;                 // literal 8, photon.cpp:411
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    const float* cosT = tables; const float* sinT = tables + 256;
-    const float* cosP = tables + 512; const float* sinP = tables + 768;
-    auto add_power = [&](unsigned idx, unsigned pk, bool own, bool on) {    // one photon's power if it is not E and faces the surface
-        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (on) {
-            w4 = *reinterpret_cast<const float4*>(pq + idx);               // power + the reference's slot
-            if (!own) pk = pp[idx].packed;                                 // theta / phi of a child visited at its parent
-        }
-        const bool member = on && __float_as_int(w4.w) != E;
-        members += member ? 1 : 0;
-        const int theta = (pk >> 8) & 255, phi = (pk >> 16) & 255;
-        const float dx = sinT[theta] * cosP[phi], dy = sinT[theta] * sinP[phi], dz = cosT[theta];
-        if (member && (dx * nx + dy * ny + dz * nz) < 0.0f) { r += w4.x; g += w4.y; b += w4.z; }
-    };
-    if (__ballot(summing) != 0ull) {
-        if (summing) { nx = nrm3[3 * qi]; ny = nrm3[3 * qi + 1]; nz = nrm3[3 * qi + 2]; }
-        lane_walk(summing, [&]() { return U; },
-                  [&](float d2, unsigned idx, unsigned pk, bool own, bool al) {
-                      const unsigned key = (unsigned)__float_as_int(d2) >> 16;
-                      const bool in = al && d2 < r0 && key <= kstar && !(pk & RT_PH_UNREACHABLE);
-                      const bool below = in && key < kstar, buck = in && key == kstar;
-                      if (__ballot(below) != 0ull) {
-                          ++d_m3;
-                          n_below += below ? 1 : 0;
-                          if (below) max_below = d2 > max_below ? d2 : max_below;
-                          add_power(idx, pk, own, below);
-                      }
-                      if (__ballot(buck) != 0ull) {                        // rare: the undecided photons, by exact dist2
-                          n_bucket += buck ? 1 : 0;
-                          int x = buck ? __float_as_int(d2) : 0x7f800000; unsigned xi = idx;
-#pragma unroll
-                          for (int e = 0; e < NBK; ++e) {
-                              const bool lt = x < bk_d[e];
-                              const int td = bk_d[e]; const unsigned ti = bk_i[e];
-                              bk_d[e] = lt ? x : td; bk_i[e] = lt ? xi : ti;
-                              x = lt ? td : x; xi = lt ? ti : xi;
-                          }
-                      }
-                  }, d_v3);
-    }
-    // the exact k-th and (k+1)-th smallest dist2, the reference's final radius, and the bucket's share of the sum
-    float T = r0;
-    if (summing) {
-        if (evict) {
-            const int j = k - n_below;                                     // members still to come from the bucket
-            if (j < 0 || j >= NBK || n_bucket > NBK || n_below + n_bucket < k + 1) ambiguous = true;
-            else {
-                float kth = max_below, k1th = __int_as_float(bk_d[0]);
-#pragma unroll
-                for (int e = 1; e < NBK; ++e) if (e <= j) { kth = __int_as_float(bk_d[e - 1]); k1th = __int_as_float(bk_d[e]); }
-                T = dE <= kth ? k1th : kth;                                // S \ {E}: if E is one of the k nearest, the (k+1)-th takes its place
-            }
-        } else if (n_bucket != 0) ambiguous = true;                        // (cannot happen: fewer than k + 1 candidates leave K* at +inf)
-    }
-    if (__ballot(summing && !ambiguous && n_bucket > 0) != 0ull) {
-#pragma unroll
-        for (int e = 0; e < NBK; ++e) {
-            const bool on = summing && !ambiguous && e < n_bucket && __int_as_float(bk_d[e]) <= T;
-            if (__ballot(on) != 0ull) add_power(bk_i[e], 0u, false, on);
-        }
-    }
-    if (summing && !ambiguous) {
-        if (members != found) ambiguous = true;                            // more (or fewer) photons within T than k: a tie
-        const float tmp = (float)(((double)1.0f / 3.141592) / (double)T);  // (1.0f/PI)/(np.dist2[0])
-        r *= tmp; g *= tmp; b *= tmp;
-    }
-    if (dbg) {
-        const unsigned long long fl = __popcll(__ballot(valid && ambiguous));
-        unsigned long long p1 = d_p1;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) p1 += __shfl_xor(p1, off, 64);
-        if (lane == 0) {
-            atomicAdd(dbg + 0, p1);
-            atomicAdd(dbg + 1, (unsigned long long)d_v2); atomicAdd(dbg + 2, (unsigned long long)d_c2);
-            atomicAdd(dbg + 3, (unsigned long long)d_v3); atomicAdd(dbg + 4, (unsigned long long)d_m3); atomicAdd(dbg + 5, fl);
-            atomicAdd(dbg + 6, 1ull);
-            const unsigned long long dt = (unsigned long long)(wall_clock64() - t_begin);
-            atomicAdd(dbg + 7, dt);
-            atomicMax(dbg + 8, (dt << 24) | (unsigned long long)(d_v2 > 0xffffffu ? 0xffffffu : d_v2));
-            if (dt > 100000ull) atomicAdd(dbg + 9, 1ull);
-            if (dt > 1000000ull) atomicAdd(dbg + 10, 1ull);
-            atomicAdd(dbg + 12, (unsigned long long)d_lanes);
-        }
-    }
-    if (valid) {
-        if (ambiguous || !summing) { r = 0.f; g = 0.f; b = 0.f; }
-        out_rgb[3 * qi] = r; out_rgb[3 * qi + 1] = g; out_rgb[3 * qi + 2] = b;
-        if (ambiguous) redo_list[atomicAdd(redo_count, 1u)] = (int32_t)qi;
-    }
-}
-
 namespace {
 struct WaveWork {            // carved from the caller's workspace
     unsigned *keys_in, *keys_out; int32_t *vals_in, *vals_out; void* temp; size_t temp_bytes, total;
@@ -931,14 +607,7 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
     if (lane_walk) { group = 64; }
     const unsigned grid2 = (unsigned)((q + group - 1) / group);
 #define WAVE_ARGS dim3(grid2), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_redo_list, d_redo_count, perm, budget, group, d_stats
-    // the per-lane walk with 16-bit keys (k_irr_lane16): default for k <= 103; RT_KNN_LIST=f32 keeps the 32-bit list
-    static const bool f32_list = [] { const char* e = getenv("RT_KNN_LIST"); return e && strcmp(e, "f32") == 0; }();
-    if (lane_walk && !f32_list && k <= 103) {
-#define LANE16_ARGS dim3(grid2), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, d_redo_list, d_redo_count, perm, d_stats
-        if (k <= 39) hipLaunchKernelGGL((k_irr_lane16<20>), LANE16_ARGS);
-        else hipLaunchKernelGGL((k_irr_lane16<52>), LANE16_ARGS);
-#undef LANE16_ARGS
-    } else if (lane_walk) {
+    if (lane_walk) {
         if (k <= 31) hipLaunchKernelGGL((k_irr_main<32, true>), WAVE_ARGS);
         else if (k <= 63) hipLaunchKernelGGL((k_irr_main<64, true>), WAVE_ARGS);
         else if (k <= 103) hipLaunchKernelGGL((k_irr_main<104, true>), WAVE_ARGS);
