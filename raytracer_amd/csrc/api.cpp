@@ -58,8 +58,9 @@ int rt_scene::scratch(int slot, size_t bytes, void** p) {
     return RT_OK;
 }
 
-template <class T>
-static int upload(rt_scene* s, const std::vector<T>& v, const T** out) {
+template <class V, class T>
+static int upload(rt_scene* s, const V& v, const T** out) {
+    static_assert(std::is_same<typename V::value_type, T>::value, "upload: element type");
     void* p = nullptr;
     int rc = s->dev_alloc(&p, v.size() * sizeof(T));
     if (rc) return rc;
@@ -470,7 +471,7 @@ extern "C" int64_t rt_host_flat_get(const rt_host_flat* f, int which, void* dst,
             case 2: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].meta; break;
             case 3: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].leaf_first; break;
             case 4: ((int32_t*)dst)[i] = h.nodes[7][(size_t)i].leaf_count; break;
-            case 5: ((int32_t*)dst)[h.leaf_tris[(size_t)i].rank] = h.leaf_tris[(size_t)i].prim; break;   // in visit-rank order
+            case 5: ((int32_t*)dst)[i] = h.rank_prim[(size_t)i]; break;                                 // in visit-rank order
             case 6: ((int32_t*)dst)[i] = h.loose[(size_t)i].prim; break;
             case 7: memcpy((float*)dst + 9 * (size_t)h.leaf_tris[(size_t)i].rank, h.leaf_tris[(size_t)i].v0, 36); break;
         }
@@ -479,3 +480,31 @@ extern "C" int64_t rt_host_flat_get(const rt_host_flat* f, int which, void* dst,
 }
 
 extern "C" void rt_host_flat_free(rt_host_flat* f) { delete f; }
+
+// tools/time_host_build.py, tests/test_host_build.py: the host half of rt_scene_create (both hierarchies) with no device, for
+// timing the builders and for checking that their output does not depend on the number of threads.  *digest (may be
+// NULL): a hash of every array of the flattened scene.
+extern "C" int rt_debug_host_build(const rt_scene_desc* d, uint64_t* digest) {
+    if (!d) return rt_fail(RT_E_INVALID, "rt_debug_host_build: NULL argument");
+    HostFlatScene flat;
+    std::string err;
+    int rc = rt_build_flat_scene(d, &flat, &err);
+    if (!rc) rc = rt_build_bvh(d, &flat, &err);
+    if (rc) return rt_fail(rc, "%s", err.c_str());
+    if (digest) {
+        uint64_t h = 1469598103934665603ull;
+        auto add = [&h](const void* p, size_t bytes) {
+            const unsigned char* c = (const unsigned char*)p;
+            size_t i = 0;
+            for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, c + i, 8); h = (h ^ w) * 1099511628211ull; }
+            for (; i < bytes; ++i) h = (h ^ c[i]) * 1099511628211ull;
+            h = (h ^ bytes) * 1099511628211ull;
+        };
+        auto vec = [&add](const auto& v) { add(v.data(), v.size() * sizeof(v[0])); };
+        for (int o = 0; o < 8; ++o) { vec(flat.nodes[o]); vec(flat.bvh_nodes[o]); }
+        vec(flat.leaf_tris); vec(flat.leaf_groups); vec(flat.rank_prim); vec(flat.loose); vec(flat.bvh_c32); vec(flat.bvh_tris);
+        vec(flat.bvh_tri_ref); vec(flat.bvh_ref_leaf); vec(flat.ref_parent); vec(flat.ref_chain_box); vec(flat.prim_normal); vec(flat.prim_geom);
+        *digest = h;
+    }
+    return RT_OK;
+}

@@ -2,7 +2,9 @@
 // the HIP kernels (kernels.hip) of librt_hip.so.  Not part of the ABI.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/rt_hip.h"
 
@@ -174,21 +176,34 @@ struct DevSceneView {       // passed by value to kernels
 
 // ---------------------------------------------------------------------------
 // host-side flattened scene produced by scene_build.cpp
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the builders fill every element they
+// size, and zero-filling gigabytes on one thread first costs more than the fill itself
+template <class T>
+struct rt_default_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = rt_default_init_alloc<U>; };
+    rt_default_init_alloc() = default;
+    template <class U> rt_default_init_alloc(const rt_default_init_alloc<U>&) {}
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <class T> using rt_uvec = std::vector<T, rt_default_init_alloc<T>>;
+
 struct HostFlatScene {
-    std::vector<DevNode> nodes[8];             // nodes[7] is the reference order
-    std::vector<DevLeafTri> leaf_tris;
-    std::vector<DevLeafGroup> leaf_groups;
+    rt_uvec<DevNode> nodes[8];                 // nodes[7] is the reference order
+    rt_uvec<DevLeafTri> leaf_tris;
+    rt_uvec<DevLeafGroup> leaf_groups;
+    rt_uvec<int32_t> rank_prim;                // the triangle (scene prim) of the leaf record with visit rank r
     std::vector<DevLoose> loose;
-    std::vector<DevBvhNode> bvh_nodes[8];      // bvh_build.cpp
-    std::vector<DevBvhNode32> bvh_c32;
-    std::vector<DevLeafTri> bvh_tris;
-    std::vector<int32_t> bvh_tri_ref;
-    std::vector<DevRefLeaf> bvh_ref_leaf;
-    std::vector<int32_t> ref_parent;
-    std::vector<float> ref_chain_box;
+    rt_uvec<DevBvhNode> bvh_nodes[8];          // bvh_build.cpp
+    rt_uvec<DevBvhNode32> bvh_c32;
+    rt_uvec<DevLeafTri> bvh_tris;
+    rt_uvec<int32_t> bvh_tri_ref;
+    rt_uvec<DevRefLeaf> bvh_ref_leaf;
+    rt_uvec<int32_t> ref_parent;
+    rt_uvec<float> ref_chain_box;
     float bvh_root_centre[3] = {0.f, 0.f, 0.f};
-    std::vector<float> prim_normal;
-    std::vector<float> prim_geom;
+    rt_uvec<float> prim_normal;
+    rt_uvec<float> prim_geom;
     int64_t kd_nodes_built = 0;
     int32_t kd_max_depth = 0;
     int64_t ntri = 0, nsphere = 0;

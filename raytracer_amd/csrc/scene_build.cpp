@@ -4,6 +4,7 @@
 // described in rt_internal.h.  Runs once per scene on the host; the result is
 // uploaded to HBM by api.cpp.
 #include "rt_internal.h"
+#include "host_par.h"
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -37,31 +38,42 @@ struct BuildNode {
     // filled while flattening in reference order, reused by the other seven layouts
     int32_t leaf_first = 0, group_first = 0;
     float margin = 0.f;
-    // a leaf's records and groups, made in parallel (ranks relative to the leaf), appended in reference order
-    std::vector<DevLeafTri> tris;
-    std::vector<DevLeafGroup> groups;
 };
 
-// The two subtrees of a node are independent (own primitive lists, own counters folded in at the end), so large
-// ones are built on their own threads; the tree does not depend on the schedule.
+// The tree does not depend on the schedule.  Nodes of at least `par_step` triangles -- the top of the tree, where there
+// are fewer nodes than threads -- are split one after another by all threads together (bounds, the split value as an
+// exact order statistic, the two lists); the subtrees below them are independent tasks, each built by one thread.
 struct Builder {
     const rt_prim* prims;
-    size_t par_min;                  // nodes with at least this many triangles give one child to a new thread
+    int nt;
+    size_t par_step;
     std::atomic<int64_t> built{0};
     std::atomic<int32_t> max_depth{0};
+    struct Task { BuildNode* n; int depth; };
+    std::vector<Task> tasks;
+
+    int threads_for(size_t cnt) const { return (int)std::max<size_t>(1, std::min<size_t>((size_t)nt, cnt >> 16)); }
 
     // CalcBound, hw4.cpp:330-389
-    void bound(BuildNode& n) const {
+    void bound(BuildNode& n, int th) const {
+        struct MM { float mn[3], mx[3]; };
+        std::vector<MM> part((size_t)th);
+        rt_parallel_chunks((int64_t)n.prims.size(), th, [&](int c, int64_t a, int64_t b) {
+            float mn[3] = {1e9f, 1e9f, 1e9f}, mx[3] = {-1e9f, -1e9f, -1e9f};
+            for (int64_t i = a; i < b; ++i) {
+                const float* f = prims[n.prims[(size_t)i]].f;
+                for (int j = 0; j < 3; ++j)
+                    for (int k = 0; k < 3; ++k) {
+                        float v = f[3 * j + k];
+                        if (v < mn[k]) mn[k] = v;
+                        if (v > mx[k]) mx[k] = v;
+                    }
+            }
+            memcpy(part[(size_t)c].mn, mn, 12); memcpy(part[(size_t)c].mx, mx, 12);
+        });
         float mn[3] = {1e9f, 1e9f, 1e9f}, mx[3] = {-1e9f, -1e9f, -1e9f};
-        for (int32_t id : n.prims) {
-            const float* f = prims[id].f;
-            for (int j = 0; j < 3; ++j)
-                for (int k = 0; k < 3; ++k) {
-                    float v = f[3 * j + k];
-                    if (v < mn[k]) mn[k] = v;
-                    if (v > mx[k]) mx[k] = v;
-                }
-        }
+        for (const MM& p : part)
+            for (int k = 0; k < 3; ++k) { if (p.mn[k] < mn[k]) mn[k] = p.mn[k]; if (p.mx[k] > mx[k]) mx[k] = p.mx[k]; }
         const float half = inv_via_double(2.0f);           // operator/(vec3, 2.0f)
         for (int k = 0; k < 3; ++k) {
             n.center[k] = (mn[k] + mx[k]) * half;
@@ -72,52 +84,99 @@ struct Builder {
             if (n.extend[k] > best) { best = n.extend[k]; n.axis = k; }
     }
 
-    // BuildKD, hw4.cpp:393-490.  The reference sorts every vertex coordinate on
-    // the split axis and takes element size/2; nth_element yields the same value.
-    void build(BuildNode& n, int depth) {
+    // One step of BuildKD, hw4.cpp:393-490, with `th` threads.  The reference sorts every vertex coordinate on the split
+    // axis and takes element size/2: the order statistic, which nth_element (one thread) and the radix select (many)
+    // both return.  True: the node was subdivided.
+    bool split(BuildNode& n, int depth, int th) {
         for (int32_t cur = max_depth.load(); depth > cur && !max_depth.compare_exchange_weak(cur, depth);) {}
         built.fetch_add(1);
-        bound(n);
+        bound(n, th);
         const int ax = n.axis;
-        std::vector<float> coord;
-        coord.reserve(n.prims.size() * 3);
-        for (int32_t id : n.prims) {
-            const float* f = prims[id].f;
-            coord.push_back(f[ax]); coord.push_back(f[3 + ax]); coord.push_back(f[6 + ax]);
+        const int64_t cnt = (int64_t)n.prims.size();
+        float split;
+        if (th <= 1) {
+            static thread_local std::vector<float> coord, buf;
+            coord.resize((size_t)cnt * 3);
+            for (int64_t i = 0; i < cnt; ++i) {
+                const float* f = prims[n.prims[(size_t)i]].f;
+                coord[(size_t)i * 3] = f[ax]; coord[(size_t)i * 3 + 1] = f[3 + ax]; coord[(size_t)i * 3 + 2] = f[6 + ax];
+            }
+            split = rt_select_serial(coord.data(), cnt * 3, (cnt * 3) / 2, buf);
+        } else {
+            split = rt_parallel_select(cnt, th, (cnt * 3) / 2, [this, &n, ax](int64_t i, auto emit) {
+                const float* f = prims[n.prims[(size_t)i]].f;
+                emit(f[ax]); emit(f[3 + ax]); emit(f[6 + ax]);
+            });
         }
-        const size_t mid = coord.size() / 2;
-        std::nth_element(coord.begin(), coord.begin() + (ptrdiff_t)mid, coord.end());
-        const float split = coord[mid];
-        std::vector<float>().swap(coord);
-
         n.left.reset(new BuildNode());
         n.right.reset(new BuildNode());
-        size_t both = 0;
-        for (int32_t id : n.prims) {
+        auto sides = [this, ax, split](int32_t id, bool& l, bool& r) {
             const float* f = prims[id].f;
-            const bool r = f[ax] >= split || f[3 + ax] >= split || f[6 + ax] >= split;
-            const bool l = f[ax] < split || f[3 + ax] < split || f[6 + ax] < split;
-            if (r) n.right->prims.push_back(id);
-            if (l) n.left->prims.push_back(id);
-            both += (l && r);
+            r = f[ax] >= split || f[3 + ax] >= split || f[6 + ax] >= split;
+            l = f[ax] < split || f[3 + ax] < split || f[6 + ax] < split;
+        };
+        size_t both = 0;
+        if (th <= 1) {
+            static thread_local std::vector<int32_t> ll, rr;
+            ll.clear(); rr.clear();
+            for (int32_t id : n.prims) {
+                bool l, r; sides(id, l, r);
+                if (r) rr.push_back(id);
+                if (l) ll.push_back(id);
+                both += (l && r);
+            }
+            n.left->prims.assign(ll.begin(), ll.end()); n.right->prims.assign(rr.begin(), rr.end());
+        } else {
+            struct Cnt { int64_t l, r, both; };
+            std::vector<Cnt> part((size_t)th + 1, Cnt{0, 0, 0});
+            rt_parallel_chunks(cnt, th, [&](int c, int64_t a, int64_t b) {
+                Cnt k{0, 0, 0};
+                for (int64_t i = a; i < b; ++i) { bool l, r; sides(n.prims[(size_t)i], l, r); k.l += l; k.r += r; k.both += (l && r); }
+                part[(size_t)c + 1] = k;
+            });
+            for (int c = 0; c < th; ++c) { part[(size_t)c + 1].l += part[(size_t)c].l; part[(size_t)c + 1].r += part[(size_t)c].r; part[(size_t)c + 1].both += part[(size_t)c].both; }
+            n.left->prims.resize((size_t)part[(size_t)th].l); n.right->prims.resize((size_t)part[(size_t)th].r);
+            both = (size_t)part[(size_t)th].both;
+            rt_parallel_chunks(cnt, th, [&](int c, int64_t a, int64_t b) {
+                int64_t pl = part[(size_t)c].l, pr = part[(size_t)c].r;
+                for (int64_t i = a; i < b; ++i) {
+                    const int32_t id = n.prims[(size_t)i];
+                    bool l, r; sides(id, l, r);
+                    if (r) n.right->prims[(size_t)pr++] = id;
+                    if (l) n.left->prims[(size_t)pl++] = id;
+                }
+            });
         }
         const bool subdivide = (float)both < (float)n.left->prims.size() / n.model_scale &&
                                (float)both < (float)n.right->prims.size() / n.model_scale;
         if (subdivide) {
-            const bool fork = n.prims.size() >= par_min;
             std::vector<int32_t>().swap(n.prims);       // interior lists are never read by traversal
-            if (fork) {
-                std::thread other([this, &n, depth] { build(*n.left, depth + 1); });
-                build(*n.right, depth + 1);
-                other.join();
-            } else {
-                build(*n.left, depth + 1);
-                build(*n.right, depth + 1);
-            }
         } else {
             n.leaf = true;                              // hw4.cpp:484: this node tests its own list
             n.left.reset(); n.right.reset();            // its children are never visited (hw4.cpp:827)
         }
+        return subdivide;
+    }
+
+    void build(BuildNode& n, int depth) {               // one thread, the whole subtree
+        if (!split(n, depth, 1)) return;
+        build(*n.left, depth + 1);
+        build(*n.right, depth + 1);
+    }
+
+    void build_top(BuildNode& n, int depth) {
+        if (n.prims.size() < par_step) { tasks.push_back(Task{&n, depth}); return; }
+        if (!split(n, depth, threads_for(n.prims.size()))) return;
+        build_top(*n.left, depth + 1);
+        build_top(*n.right, depth + 1);
+    }
+
+    void run(BuildNode& root) {
+        const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        build_top(root, 0);
+        if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "KD top: %.2f s, %zu tasks\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0, tasks.size());
+        std::stable_sort(tasks.begin(), tasks.end(), [](const Task& a, const Task& b) { return a.n->prims.size() > b.n->prims.size(); });
+        rt_parallel_tasks((int64_t)tasks.size(), nt, [this](int64_t i) { build(*tasks[(size_t)i].n, tasks[(size_t)i].depth); });
     }
 };
 
@@ -132,15 +191,14 @@ void fill_tri(float* a, const float* f) {
 struct Flattener {
     const rt_scene_desc* d;
     HostFlatScene* out;
+    float dbg_slack;                 // RT_DEBUG_SLACK_SCALE, read once per build
 
-    // Reference order (layout 7): pre-order with the RIGHT child first, the order in which the reference
-    // pops nodes (hw4.cpp:831-836).  Emits the leaf records (their index is the reference's visit rank)
-    // and computes the culling slack of every subtree.
-    // the records and groups of one leaf: the reference's list order gives the rank, a Morton curve the storage order
-    void make_leaf(BuildNode& n) const {
-        struct Ref { uint32_t code; int32_t k; };
-        std::vector<Ref> refs(n.prims.size());
-        for (size_t k = 0; k < n.prims.size(); ++k) {
+    // The records and groups of one leaf, written in place at the leaf's offsets (leaf_first = the reference's visit rank
+    // of its first record): the reference's list order gives the rank, a Morton curve the storage order.
+    void make_leaf(BuildNode& n, std::vector<uint64_t>& refs) const {
+        const size_t cnt = n.prims.size();
+        refs.resize(cnt);
+        for (size_t k = 0; k < cnt; ++k) {
             const float* f = d->prims[n.prims[k]].f;
             uint32_t code = 0;
             for (int ax = 0; ax < 3; ++ax) {
@@ -152,29 +210,32 @@ struct Flattener {
                 q = (q | (q << 4)) & 0x030C30C3; q = (q | (q << 2)) & 0x09249249;
                 code |= q << ax;
             }
-            refs[k] = Ref{code, (int32_t)k};
+            refs[k] = (uint64_t)code << 32 | (uint64_t)k;          // by code, ties in list order
+            out->rank_prim[(size_t)n.leaf_first + k] = n.prims[k];
         }
-        std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.code < b.code; });
+        std::sort(refs.begin(), refs.end());
         float margin = 0.f;
-        n.tris.reserve(refs.size());
-        n.groups.reserve((refs.size() + RT_GROUP - 1) / RT_GROUP);
-        for (size_t g0 = 0; g0 < refs.size(); g0 += RT_GROUP) {
+        DevLeafTri* tris = &out->leaf_tris[(size_t)n.leaf_first];
+        DevLeafGroup* groups = out->leaf_groups.data() + (size_t)n.group_first;
+        const float slack_scale = dbg_slack;
+        for (size_t g0 = 0; g0 < cnt; g0 += RT_GROUP) {
             DevLeafGroup g{};
             for (int k = 0; k < 3; ++k) { g.lo[k] = 1e30f; g.hi[k] = -1e30f; }
             float gm = 0.f;
             double amin = 1e300, ax[3] = {0, 0, 0};
             std::array<std::array<double, 3>, RT_GROUP> nrm;
             int nn = 0;
-            for (size_t j = g0; j < std::min(refs.size(), g0 + RT_GROUP); ++j) {
-                const int32_t id = n.prims[(size_t)refs[j].k];
+            for (size_t j = g0; j < std::min(cnt, g0 + RT_GROUP); ++j) {
+                const int32_t k0 = (int32_t)(refs[j] & 0xffffffffu);
+                const int32_t id = n.prims[(size_t)k0];
                 const float* f = d->prims[id].f;
-                DevLeafTri t{};
+                DevLeafTri t;
                 float a[9]; fill_tri(a, f);
                 memcpy(t.v0, a, 12); memcpy(t.e1, a + 3, 12); memcpy(t.e2, a + 6, 12);
                 t.prim = id;
                 t.flags = ((double)d->materials[d->prim_material[id]].refract > 0.1) ? RT_PF_SKIP_SHADOW : 0;
-                t.rank = refs[j].k;                              // + leaf_first when the leaf is appended
-                n.tris.push_back(t);
+                t.rank = n.leaf_first + k0;
+                tris[j] = t;
                 for (int v = 0; v < 3; ++v)
                     for (int k = 0; k < 3; ++k) { g.lo[k] = std::min(g.lo[k], f[3 * v + k]); g.hi[k] = std::max(g.hi[k], f[3 * v + k]); }
                 // |edge1|*|edge2| bounds the cancellation in det and in the t / u / v numerators
@@ -195,7 +256,7 @@ struct Flattener {
             }
             // RT_DEBUG_SLACK_SCALE (tests only; 1 in the product) shrinks the lateral inflation of the group boxes, which
             // lateral_slack (trace_device.h) takes in proportion to gm; the distance-culling margin below keeps the real gm
-            g.gm = gm * dbg_slack_scale();
+            g.gm = gm * slack_scale;
             const double al = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
             double cmin = 0.0;
             if (al > 1e-12 && nn > 0) {
@@ -216,7 +277,7 @@ struct Flattener {
             // leaf's box by the group's L1 diagonal, plus 0.44 (|e1| + |e2|) <= 0.88 of that diagonal
             g.pad[1] = 1.9f * ((g.hi[0] - g.lo[0]) + (g.hi[1] - g.lo[1]) + (g.hi[2] - g.lo[2]));
             margin = std::max(margin, gm);
-            n.groups.push_back(g);
+            groups[g0 / RT_GROUP] = g;
         }
         n.margin = margin;
     }
@@ -227,40 +288,31 @@ struct Flattener {
         collect_leaves(*n.left, leaves);
     }
 
-    // every leaf's records, in parallel (leaves are dealt round-robin: neighbours have similar sizes), then placed
-    // in the reference's leaf order (leaf_first = the reference's visit rank of the leaf's first record)
+    // every leaf's offsets in the reference's leaf order, then the records of blocks of leaves in parallel
     void make_leaves(BuildNode& root) const {
         std::vector<BuildNode*> leaves;
         collect_leaves(root, leaves);
-        const int nt = leaves.size() < 256 ? 1 : rt_host_threads();
-        auto each = [&](auto fn) {
-            if (nt <= 1) { for (BuildNode* l : leaves) fn(*l); return; }
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; ++t)
-                th.emplace_back([&leaves, &fn, t, nt] { for (size_t i = (size_t)t; i < leaves.size(); i += (size_t)nt) fn(*leaves[i]); });
-            for (std::thread& t : th) t.join();
-        };
-        each([this](BuildNode& l) { make_leaf(l); });
         size_t refs = out->leaf_tris.size(), groups = out->leaf_groups.size();
         for (BuildNode* l : leaves) {
             l->leaf_first = (int32_t)refs; l->group_first = (int32_t)groups;
-            refs += l->tris.size(); groups += l->groups.size();
+            refs += l->prims.size(); groups += (l->prims.size() + RT_GROUP - 1) / RT_GROUP;
         }
         out->leaf_tris.resize(refs);
         out->leaf_groups.resize(groups);
-        each([this](BuildNode& l) {
-            for (DevLeafTri& t : l.tris) t.rank += l.leaf_first;
-            if (!l.tris.empty()) memcpy(&out->leaf_tris[(size_t)l.leaf_first], l.tris.data(), l.tris.size() * sizeof(DevLeafTri));
-            if (!l.groups.empty()) memcpy(&out->leaf_groups[(size_t)l.group_first], l.groups.data(), l.groups.size() * sizeof(DevLeafGroup));
-            std::vector<DevLeafTri>().swap(l.tris);
-            std::vector<DevLeafGroup>().swap(l.groups);
+        out->rank_prim.resize(refs);
+        const int nt = leaves.size() < 256 ? 1 : rt_host_threads();
+        constexpr int64_t BLOCK = 128;
+        const int64_t nblock = ((int64_t)leaves.size() + BLOCK - 1) / BLOCK;
+        rt_parallel_tasks(nblock, nt, [this, &leaves](int64_t blk) {
+            std::vector<uint64_t> scratch;
+            for (size_t i = (size_t)(blk * BLOCK); i < std::min(leaves.size(), (size_t)((blk + 1) * BLOCK)); ++i) make_leaf(*leaves[i], scratch);
         });
     }
 
     // Reference order (layout 7): pre-order with the RIGHT child first, the order in which the reference
     // pops nodes (hw4.cpp:831-836); folds the culling slack of every subtree.
     int32_t emit_reference(BuildNode& n, int depth) {
-        std::vector<DevNode>& nodes = out->nodes[7];
+        rt_uvec<DevNode>& nodes = out->nodes[7];
         const int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         if (!n.leaf) {
@@ -276,7 +328,7 @@ struct Flattener {
     // Layout o: the child on the side the ray comes from goes first (bit a of o: direction negative on axis a,
     // so the larger-coordinate child, `right`, is nearer).
     void emit_octant(const BuildNode& n, int depth, int o) {
-        std::vector<DevNode>& nodes = out->nodes[o];
+        rt_uvec<DevNode>& nodes = out->nodes[o];
         const size_t me = nodes.size();
         nodes.emplace_back();
         if (!n.leaf) {
@@ -335,15 +387,17 @@ int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string*
         root.model_scale = tempF < 1.5f ? 1.5f : tempF;
         const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         const int nt = rt_host_threads();
-        Builder b{d->prims, nt > 1 ? std::max<size_t>((size_t)1 << 15, root.prims.size() / (size_t)(4 * nt)) : SIZE_MAX};
-        b.build(root, 0);
+        Builder b;
+        b.prims = d->prims; b.nt = nt;
+        b.par_step = nt > 1 ? std::max<size_t>((size_t)1 << 16, root.prims.size() / (size_t)(4 * nt)) : SIZE_MAX;
+        b.run(root);
         out->kd_nodes_built += b.built.load();
         out->kd_max_depth = std::max(out->kd_max_depth, b.max_depth.load());
         if (b.max_depth.load() + 1 > 250) { *err = "KD-tree deeper than 250 levels"; return RT_E_LIMIT; }
         const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t1 = now();
-        Flattener f{d, out};
+        Flattener f{d, out, dbg_slack_scale()};
         for (int o = 0; o < 8; ++o) out->nodes[o].reserve(out->nodes[o].size() + (size_t)b.built.load());
         f.make_leaves(root);
         const double t2 = now();
@@ -363,10 +417,14 @@ int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string*
             *err = "scene exceeds 2^30 nodes or leaf references"; return RT_E_LIMIT;
         }
     }
-    out->prim_normal.assign((size_t)np * 3, 0.f);
-    out->prim_geom.assign((size_t)np * 4, 0.f);
+    out->prim_normal.resize((size_t)np * 3);
+    out->prim_geom.resize((size_t)np * 4);
     {
         auto tables = [d, out](int64_t a, int64_t b) {
+            if (b > a) {
+                memset(&out->prim_normal[(size_t)a * 3], 0, (size_t)(b - a) * 12);
+                memset(&out->prim_geom[(size_t)a * 4], 0, (size_t)(b - a) * 16);
+            }
             for (int64_t i = a; i < b; ++i) {
                 const float* f = d->prims[i].f;
                 if (d->prim_type[i] == RT_PRIM_TRIANGLE) {
