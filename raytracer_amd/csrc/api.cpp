@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 static thread_local std::string g_err;
 
@@ -161,6 +162,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HostFlatScene flat;
     std::string err;
     int rc;
+    // RT_HOST_LAYOUTS=1: all eight octant layouts from the host (the device otherwise derives seven of each hierarchy);
+    // RT_CHECK_LAYOUTS=1: both, and the scene is created only if they agree byte for byte (tests/test_gpu_build.py)
+    const bool check_layouts = getenv("RT_CHECK_LAYOUTS") && atoi(getenv("RT_CHECK_LAYOUTS")) != 0;
+    const bool host_layouts = getenv("RT_HOST_LAYOUTS") && atoi(getenv("RT_HOST_LAYOUTS")) != 0;
+    flat.host_layouts = host_layouts || check_layouts;
     const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tb0 = now();
@@ -218,13 +224,48 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     DevSceneView& v = s->view;
     memset(&v, 0, sizeof v);
     rc = RT_OK;
-    for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.nodes[o], &v.nodes_oct[o]);
+    // the hierarchies: the reference trees in the reference's order (layout 7) and the BVH in layout 0 go up, the other
+    // seven layouts of each are derived there (kernels_build.hip) unless the host was asked for them
+    const int32_t nkd = (int32_t)flat.nodes[7].size(), nbvh = (int32_t)flat.bvh_nodes[0].size();
+    rc = upload(s, flat.nodes[7], &v.nodes_oct[7]);
     v.nodes = v.nodes_oct[7];
+    if (!rc && !host_layouts) {
+        DevNode* dst[7] = {};
+        for (int o = 0; o < 7 && !rc; ++o) { void* p = nullptr; rc = s->dev_alloc(&p, (size_t)nkd * sizeof(DevNode)); dst[o] = (DevNode*)p; v.nodes_oct[o] = dst[o]; }
+        flat.kd_roots.push_back(nkd);
+        const int32_t* d_roots = nullptr;
+        if (!rc) rc = upload(s, flat.kd_roots, &d_roots);
+        if (!rc) { hipError_t e = rtk_kd_layouts(v.nodes_oct[7], nkd, d_roots, (int32_t)flat.kd_roots.size() - 1, dst, nullptr); if (e != hipSuccess) rc = rt_hipfail(e, "k_kd_layouts"); }
+    } else {
+        for (int o = 0; o < 7 && !rc; ++o) rc = upload(s, flat.nodes[o], &v.nodes_oct[o]);
+    }
     if (!rc) rc = upload(s, flat.leaf_tris, &v.leaf_tris);
     if (!rc) rc = upload(s, flat.leaf_groups, &v.leaf_groups);
     if (!rc) rc = upload(s, flat.loose, &v.loose);
-    for (int o = 0; o < 8 && !rc; ++o) rc = upload(s, flat.bvh_nodes[o], &v.bvh_oct[o]);
-    v.nbvh = (int32_t)flat.bvh_nodes[0].size();
+    if (!rc) rc = upload(s, flat.bvh_nodes[0], &v.bvh_oct[0]);
+    if (!rc && !host_layouts) {
+        DevBvhNode* dst[8] = {};
+        for (int o = 1; o < 8 && !rc; ++o) { void* p = nullptr; rc = s->dev_alloc(&p, (size_t)nbvh * sizeof(DevBvhNode)); dst[o] = (DevBvhNode*)p; v.bvh_oct[o] = dst[o]; }
+        if (!rc) { hipError_t e = rtk_bvh_layouts(v.bvh_oct[0], nbvh, dst, nullptr); if (e != hipSuccess) rc = rt_hipfail(e, "k_bvh_layouts"); }
+    } else {
+        for (int o = 1; o < 8 && !rc; ++o) rc = upload(s, flat.bvh_nodes[o], &v.bvh_oct[o]);
+    }
+    if (!rc && !host_layouts) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = rt_hipfail(e, "octant layouts");
+    }
+    if (!rc && check_layouts && !host_layouts) {                  // the device's layouts against the host's, byte for byte
+        std::vector<unsigned char> got;
+        for (int o = 0; o < 8 && !rc; ++o) {
+            got.resize((size_t)nkd * sizeof(DevNode));
+            if (nkd && (hipMemcpy(got.data(), v.nodes_oct[o], got.size(), hipMemcpyDeviceToHost) != hipSuccess || memcmp(got.data(), flat.nodes[o].data(), got.size()) != 0))
+                rc = rt_fail(RT_E_INVALID, "RT_CHECK_LAYOUTS: layout %d of the reference trees differs from the host's", o);
+            got.resize((size_t)nbvh * sizeof(DevBvhNode));
+            if (!rc && nbvh && (hipMemcpy(got.data(), v.bvh_oct[o], got.size(), hipMemcpyDeviceToHost) != hipSuccess || memcmp(got.data(), flat.bvh_nodes[o].data(), got.size()) != 0))
+                rc = rt_fail(RT_E_INVALID, "RT_CHECK_LAYOUTS: layout %d of the BVH differs from the host's", o);
+        }
+    }
+    v.nbvh = nbvh;
     if (!rc && !flat.bvh_c32.empty()) rc = upload(s, flat.bvh_c32, &v.bvh_c32);
     memcpy(v.bvh_root_centre, flat.bvh_root_centre, sizeof v.bvh_root_centre);
     v.bvh_root_rho = v.nbvh > 0 ? flat.bvh_nodes[0][0].rho : 0.f;

@@ -533,7 +533,7 @@ int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err) 
     {
         std::vector<BvhBuilder::EmitTask> todo;
         const int32_t chunk = tpar > 1 ? std::max(1024, root.size / (4 * tpar)) : INT32_MAX;
-        for (int o = 0; o < 8; ++o) {
+        for (int o = 0; o < (flat->host_layouts ? 8 : 1); ++o) {     // 1..7: derived on the device (kernels_build.hip)
             flat->bvh_nodes[o].resize((size_t)root.size);
             B.emit_top(root, 0, o, 0, croot, flat->bvh_nodes[o].data(), chunk, todo);
         }

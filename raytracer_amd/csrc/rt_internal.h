@@ -20,7 +20,7 @@ struct DevNode {            // 48 B, fetched wave-uniformly (scalar path)
     float lo[3];            // center - extend/2.0f  (hw4.cpp:287, precomputed with the same float ops)
     float hi[3];            // center + extend/2.0f
     int32_t skip;           // next node when this subtree is not entered (== index+1 for a leaf)
-    int32_t meta;           // bits 0..7 depth, bit 8 leaf
+    int32_t meta;           // bits 0..7 depth, bit 8 leaf, bits 12..13 split axis (inner nodes)
     float margin;           // relative slack for distance culling of this subtree (fast traversal)
     int32_t leaf_first;     // leaf: first record in leaf_tris (== reference visit rank of its first triangle)
     int32_t leaf_count;
@@ -76,7 +76,7 @@ struct DevBvhNode {         // 64 B
     float axis[3];          // normal cone: axis, cos, sin of the half angle (rounded outwards); valid if meta & 0x200
     float cos_t, sin_t;
     int32_t skip;           // inner node: next node when the subtree is not entered; leaf (next = index + 1): first record in bvh_tris
-    int32_t meta;           // depth | leaf << 8 | cone << 9 | (leaf: triangle count) << 16
+    int32_t meta;           // depth | leaf << 8 | cone << 9 | (inner: split axis) << 12 | (leaf: triangle count) << 16
     float rho;              // |orig - root centre| + rho >= |orig - v0| + 0.44 (|e1| + |e2|) for every triangle below
 };
 static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode must be 64 bytes");
@@ -189,7 +189,10 @@ struct rt_default_init_alloc : std::allocator<T> {
 template <class T> using rt_uvec = std::vector<T, rt_default_init_alloc<T>>;
 
 struct HostFlatScene {
-    rt_uvec<DevNode> nodes[8];                 // nodes[7] is the reference order
+    rt_uvec<DevNode> nodes[8];                 // nodes[7] is the reference order; the others are filled on the host only when
+                                               // host_layouts is set (the device derives them: kernels_build.hip)
+    std::vector<int32_t> kd_roots;             // first node of every object's tree in nodes[7]
+    bool host_layouts = false;
     rt_uvec<DevLeafTri> leaf_tris;
     rt_uvec<DevLeafGroup> leaf_groups;
     rt_uvec<int32_t> rank_prim;                // the triangle (scene prim) of the leaf record with visit rank r
@@ -249,6 +252,9 @@ hipError_t rtk_generate_tiled(const rt_camera& cam, const int32_t* d_tiles, int6
 // kernels_trace.hip: the next word group of the scene's ring of claim counters, zeroed on `st` (one ring for every
 // refilling kernel of the library, so two launches in flight never claim from the same words)
 hipError_t rtk_next_ray_counter(DevSceneView& sc, hipStream_t st);
+// kernels_build.hip: the other seven octant layouts of the reference trees (from layout 7) and of the BVH (from layout 0)
+hipError_t rtk_kd_layouts(const DevNode* src, int32_t n, const int32_t* d_roots, int32_t nroots, DevNode* const dst[7], hipStream_t st);
+hipError_t rtk_bvh_layouts(const DevBvhNode* src, int32_t n, DevBvhNode* const dst[8], hipStream_t st);
 // kernels_paths.hip: the rays of a queue with their whole subtrees of the recursion, one weighted sum per queue entry
 int rtk_paths_max_lights();
 size_t rtk_paths_stack_bytes(int64_t n, int depth0, int max_depth);

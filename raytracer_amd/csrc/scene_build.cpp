@@ -345,7 +345,7 @@ struct Flattener {
             r.lo[k] = n.center[k] - n.extend[k] / 2.0f;
             r.hi[k] = n.center[k] + n.extend[k] / 2.0f;
         }
-        r.meta = depth | (n.leaf ? 0x100 : 0);
+        r.meta = depth | (n.leaf ? 0x100 : (n.axis & 3) << 12);
         // 4x safety on the bound, plus a floor that covers the rounding of the slab arithmetic itself
         r.margin = 4.0f * n.margin + 1e-4f;
         r.leaf_first = n.leaf ? n.leaf_first : 0;
@@ -398,12 +398,14 @@ int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string*
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t1 = now();
         Flattener f{d, out, dbg_slack_scale()};
-        for (int o = 0; o < 8; ++o) out->nodes[o].reserve(out->nodes[o].size() + (size_t)b.built.load());
+        for (int o = out->host_layouts ? 0 : 7; o < 8; ++o) out->nodes[o].reserve(out->nodes[o].size() + (size_t)b.built.load());
         f.make_leaves(root);
         const double t2 = now();
+        out->kd_roots.push_back((int32_t)out->nodes[7].size());
         f.emit_reference(root, 0);
         const double t3 = now();
-        if (nt > 1 && out->nodes[7].size() > 4096) {               // the other seven layouts: one thread each
+        if (!out->host_layouts) {                                  // the device derives them (kernels_build.hip)
+        } else if (nt > 1 && out->nodes[7].size() > 4096) {        // the other seven layouts: one thread each
             std::vector<std::thread> th;
             for (int o = 0; o < 7; ++o) th.emplace_back([&f, &root, o] { f.emit_octant(root, 0, o); });
             for (std::thread& t : th) t.join();
