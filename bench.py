@@ -341,7 +341,7 @@ def knn_map(n_photons, seed=1234):
     return a, rng
 
 
-def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, steps=3, with_cpu=True):
+def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, steps=3, with_cpu=True, cpu_queries=2000):
     """BASELINE configuration 4's shape: kNN radiance lookups/s on a synthetic photon map (positions on
     the walls of the Final scene's unit box), queries on the floor/walls."""
     from raytracer_amd import abi
@@ -386,7 +386,7 @@ def knn_secondary(scene_handle, torch, n_photons, n_queries, k=100, radius=1.0, 
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
-        ns = min(2000, n_queries)
+        ns = min(cpu_queries, n_queries)
         sel = np.linspace(0, n_queries - 1, ns).astype(np.int64)
         qs = np.ascontiguousarray(q[sel]); qn = np.ascontiguousarray(nrm[sel])
         idx = np.zeros((ns, k), np.int32); d2 = np.zeros((ns, k), np.float32); fnd = np.zeros(ns, np.int32); vis = C.c_int64(0)
@@ -1213,7 +1213,7 @@ def main():
                              ("photon_frame_full", lambda: photon_frame_secondary(torch, local_rank, 10_000_000, 1_000_000, (1920, 1080), tag="photon_frame_full")),
                              # one GPU's share of BASELINE configuration 5 (scene and photon map are replicated per GPU)
                              ("stress_mesh_10m", lambda: mesh_secondary(torch, local_rank, steps=3, nu=3162, nv=1581, tag="stress_mesh_10m")),
-                             ("stress_knn_200m", lambda: knn_secondary(gs, torch, 200_000_000, args.knn_queries, steps=2, with_cpu=False))):
+                             ("stress_knn_200m", lambda: knn_secondary(gs, torch, 200_000_000, args.knn_queries, steps=2, cpu_queries=500))):
                 if not want(name):
                     continue
                 try:
