@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 on each workload of bench.py (tools/prof_target.py runs ONE workload, so a kernel name maps to one workload):
 # one --kernel-trace --stats run, then the PMC passes, each in a run of its own as the pool requires: FETCH_SIZE,
-# WRITE_SIZE, TCC hit/miss, and two SQ passes (<= 8 SQ counters each).  Output: gpurun_out/pmc/<workload>/<pass>/.
+# WRITE_SIZE, TCC hit/miss, two SQ passes (<= 8 SQ counters each) and the scalar data cache's.  Output: gpurun_out/pmc/<workload>/<pass>/.
 # tools/prof_counters.py turns that into profiles/<tag>_counters.json and profiles/<tag>_kernel_stats_<workload>.txt.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -15,7 +15,8 @@ for w in $W; do
   cp gpurun_out/pmc/kernel_source_sha.txt /tmp/sha_$w.txt
   for pass in stats FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
               "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
-              "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
+              "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" \
+              "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE"; do
     tag=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
     out=gpurun_out/pmc/$w/$tag
     rm -rf "$out"; mkdir -p "$out"

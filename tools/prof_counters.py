@@ -19,7 +19,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 base = os.path.join(ROOT, "gpurun_out", "pmc")
 outp = os.path.join(ROOT, "profiles", f"{tag}_counters.json")
 out = json.load(open(outp)) if os.path.exists(outp) else {}
@@ -67,6 +67,8 @@ for wdir in sorted(glob.glob(os.path.join(base, "*"))):
         e["launches"] = max(len(v) for v in c.values())
         e["hbm_bytes_per_launch"] = (2 * (fs or 0) + (ws or 0)) * 1024 if fs is not None else None
         e["l2_hit_rate"] = hit / (hit + miss) if hit + miss > 0 else None
+        if e.get("SQC_DCACHE_REQ"):
+            e["scalar_cache_hit_rate"] = (e.get("SQC_DCACHE_HITS") or 0.0) / e["SQC_DCACHE_REQ"]
         if k in dur:
             e["avg_us"], e["calls_in_stats_run"] = dur[k]
         t = (e.get("avg_us") or 0) * 1e-6
