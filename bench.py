@@ -492,9 +492,15 @@ def mesh_secondary(torch, local_rank, steps=5, nu=1000, nv=500, tag="mesh_1m", c
         npx = BASE_RES[0] * BASE_RES[1]
         pix = np.arange(17, npx, 211, dtype=np.int64)                 # 39 k pixels, every row and column phase
         rays = ol.oracle_primary_rays(ocam, (pix % BASE_RES[0]).astype(np.int64), (pix // BASE_RES[0]).astype(np.int64))
+        t0 = time.perf_counter()
         want = o.trace_closest(rays)["prim"]
+        port_s = time.perf_counter() - t0
         got = ids.cpu().numpy()[pix]
         o.close()
+        if cpu is None:          # no reference-binary leg for this scene (stress_mesh_10m: 1.5 GB of scene text): the oracle port, timed
+            cpu = dict(value=pix.size / port_s / 1e6, unit="Mrays/s", cores=1, kind="port", seconds=port_s,
+                       sample=f"{pix.size} primary rays of the same frame (every 211th pixel), oracle closest-hit traversal on one core, "
+                              "KD build not counted")
         parity = dict(pixels=int(pix.size), hit=int((want >= 0).sum()), mismatches=int((got != want).sum()),
                       parity_sample_ok=bool(np.array_equal(got, want)))
     except Exception as e:

@@ -30,4 +30,5 @@ for w in $W; do
     if [ $rc -ne 0 ]; then tail -n 5 "$out/stderr.txt"; exit $rc; fi
   done
   cp /tmp/sha_$w.txt gpurun_out/pmc/$w/kernel_source_sha.txt
+  python3 tools/prof_counters.py --box $w || exit 1      # summary.json instead of tens of MB of CSV (gpurun_out travels back)
 done

@@ -19,7 +19,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "r03"
 base = os.path.join(ROOT, "gpurun_out", "pmc")
 outp = os.path.join(ROOT, "profiles", f"{tag}_counters.json")
 out = json.load(open(outp)) if os.path.exists(outp) else {}
@@ -34,6 +34,32 @@ try:
 except Exception:
     head = None
 mean = lambda v: sum(v) / len(v) if v else None
+
+
+def reduce_csvs(wdir):
+    """the CSVs of one workload -> {"per": {kernel: {counter: [mean, sum, launches]}}, "stats": [[name, calls, total_ns, avg_ns, pct]]}
+    (what the rest of this script needs; small enough to travel back from the GPU box)"""
+    per = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(wdir, "*", "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    red = {k: {cn: [mean(v), sum(v), len(v)] for cn, v in c.items()} for k, c in per.items()}
+    stats = []
+    ks = os.path.join(wdir, "stats", "r_kernel_stats.csv")
+    if os.path.exists(ks):
+        for r in csv.DictReader(open(ks)):
+            stats.append([r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), r["Percentage"]])
+    return dict(per=red, stats=stats)
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--box":
+    # on the GPU box, after a workload's passes (tools/prof_all.sh): keep the summary, drop the CSVs (tens of MB)
+    wdir = os.path.join(base, sys.argv[2])
+    json.dump(reduce_csvs(wdir), open(os.path.join(wdir, "summary.json"), "w"))
+    for f in glob.glob(os.path.join(wdir, "*", "*.csv")):
+        os.remove(f)
+    sys.exit(0)
+
 for wdir in sorted(glob.glob(os.path.join(base, "*"))):
     if not os.path.isdir(wdir):
         continue
@@ -41,30 +67,27 @@ for wdir in sorted(glob.glob(os.path.join(base, "*"))):
     shaf = os.path.join(wdir, "kernel_source_sha.txt")
     meta[w] = dict(commit=head, kernel_source_sha=open(shaf).read().strip() if os.path.exists(shaf) else None,
                    reduced=time.strftime("%Y-%m-%d %H:%M"))
-    per = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(wdir, "*", "*counter_collection.csv")):
-        for row in csv.DictReader(open(f)):
-            per[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    ks = os.path.join(wdir, "stats", "r_kernel_stats.csv")
+    sm = os.path.join(wdir, "summary.json")
+    red = json.load(open(sm)) if os.path.exists(sm) else reduce_csvs(wdir)
+    per = red["per"]
     dur = {}
-    if os.path.exists(ks):
-        rows = list(csv.DictReader(open(ks)))
+    if red["stats"]:
         with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_{w}.txt"), "w") as fo:
             fo.write(f"# rocprofv3 --kernel-trace --stats -- python3 tools/prof_target.py {w}\n")
             fo.write("# kernel, calls, total_us, average_us, percent\n")
-            for r in rows:
-                fo.write(f"{r['Name'][:90]}, {r['Calls']}, {float(r['TotalDurationNs']) / 1e3:.0f}, {float(r['AverageNs']) / 1e3:.1f}, {r['Percentage']}\n")
-                dur[r["Name"]] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]))
+            for name, calls, tot, avg, pct in red["stats"]:
+                fo.write(f"{name[:90]}, {calls}, {tot / 1e3:.0f}, {avg / 1e3:.1f}, {pct}\n")
+                dur[name] = (avg / 1e3, calls)
     wout = {}
     for k, c in per.items():
         m = re.search(r"\b(k_[a-z0-9_]+(?:<[^>]*>)?)", k)
         if not m:
             continue
         name = m.group(1).replace(" ", "")
-        e = {cn: mean(v) for cn, v in c.items()}
+        e = {cn: v[0] for cn, v in c.items()}
         fs, ws = e.get("FETCH_SIZE"), e.get("WRITE_SIZE")
-        hit, miss = sum(c.get("TCC_HIT_sum", [])), sum(c.get("TCC_MISS_sum", []))
-        e["launches"] = max(len(v) for v in c.values())
+        hit, miss = c.get("TCC_HIT_sum", [0, 0, 0])[1], c.get("TCC_MISS_sum", [0, 0, 0])[1]
+        e["launches"] = max(v[2] for v in c.values())
         e["hbm_bytes_per_launch"] = (2 * (fs or 0) + (ws or 0)) * 1024 if fs is not None else None
         e["l2_hit_rate"] = hit / (hit + miss) if hit + miss > 0 else None
         if e.get("SQC_DCACHE_REQ"):
