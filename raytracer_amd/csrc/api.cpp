@@ -287,6 +287,24 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!rc) rc = upload(s, flat.bvh_ref_leaf, &v.bvh_ref_leaf);
     if (!rc) rc = upload(s, flat.ref_parent, &v.ref_parent);
     if (!rc) rc = upload(s, flat.ref_chain_box, &v.ref_chain_box);
+    // the single-step per-lane walk (trace_device.h: bvh_lane_step): its reachability records are made here, on the device
+    v.lane_step = 0; v.lane_refill_batch = 8; v.lane_acc_batch = 4; v.lane_chunk = 128;
+    if (!rc && v.bvh_c32 && !flat.bvh_tris.empty()) {
+        void* q = nullptr;
+        const int64_t nt = (int64_t)flat.bvh_tris.size();
+        rc = s->dev_alloc(&q, (size_t)nt * sizeof(DevTriReach));
+        if (!rc) {
+            v.bvh_tri_reach = (const DevTriReach*)q;
+            hipError_t e = rtk_tri_reach(v.bvh_tri_ref, v.bvh_ref_leaf, v.ref_chain_box, nt, (DevTriReach*)q, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) rc = rt_hipfail(e, "k_tri_reach");
+            v.lane_step = 1;
+        }
+    }
+    if (const char* e = getenv("RT_LANE_STEP")) v.lane_step = (atoi(e) != 0 && v.bvh_tri_reach) ? 1 : 0;
+    if (const char* e = getenv("RT_LANE_REFILL_BATCH")) { const int b = atoi(e); v.lane_refill_batch = b < 1 ? 1 : (b > 64 ? 64 : b); }
+    if (const char* e = getenv("RT_LANE_CHUNK")) { const int b = atoi(e); v.lane_chunk = b < 16 ? 16 : (b > 4096 ? 4096 : b); }
+    if (const char* e = getenv("RT_LANE_ACC_BATCH")) { const int b = atoi(e); v.lane_acc_batch = b < 1 ? 1 : (b > 64 ? 64 : b); }
     if (!rc) rc = upload(s, flat.prim_normal, &v.prim_normal);
     if (!rc) rc = upload(s, flat.prim_geom, &v.prim_geom);
     if (!rc) rc = upload(s, pmat, &v.prim_material);

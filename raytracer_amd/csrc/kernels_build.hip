@@ -81,7 +81,32 @@ __global__ __launch_bounds__(256) void k_bvh_layouts(const DevBvhNode* __restric
     }
 }
 
+// reachable_rank's first probe per BVH triangle in one 32-byte record (rt_internal.h: DevTriReach)
+__global__ __launch_bounds__(256) void k_tri_reach(const int32_t* __restrict__ tri_ref, const DevRefLeaf* __restrict__ ref_leaf,
+                                                   const float* __restrict__ chain_box, int64_t nt, DevTriReach* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nt) return;
+    DevTriReach o;
+    o.lo[0] = o.lo[1] = o.lo[2] = o.hi[0] = o.hi[1] = o.hi[2] = __builtin_nanf("");
+    o.rank = 0x7fffffff; o.pad = 0;
+    const int32_t first = tri_ref[2 * t], cnt = tri_ref[2 * t + 1];
+    if (cnt > 0) {
+        const DevRefLeaf rl = ref_leaf[first];
+        const float* cb = chain_box + 6 * (int64_t)rl.leaf;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o.lo[k] = cb[k]; o.hi[k] = cb[3 + k]; }
+        o.rank = rl.rank;
+    }
+    out[t] = o;
+}
+
 }  // namespace
+
+hipError_t rtk_tri_reach(const int32_t* tri_ref, const DevRefLeaf* ref_leaf, const float* chain_box, int64_t nt, DevTriReach* out, hipStream_t st) {
+    if (nt <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tri_reach, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tri_ref, ref_leaf, chain_box, nt, out);
+    return hipGetLastError();
+}
 
 hipError_t rtk_kd_layouts(const DevNode* src, int32_t n, const int32_t* d_roots, int32_t nroots, DevNode* const dst[7], hipStream_t st) {
     if (n <= 0) return hipSuccess;

@@ -197,6 +197,110 @@ k_trace_any_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const in
     bvh_lanes<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded, order);
 }
 
+// The same launch shape with the walk taken ONE RECORD PER WAVE STEP (trace_device.h: bvh_lane_step): every lane that
+// holds a ray fetches the record its own walk needs next, so no lane waits for another lane's way to its next leaf.
+// A finished lane writes its result at once; idle lanes claim together when sc.lane_refill_batch of them wait (a claim
+// is an atomic, a ray fetch and the per-ray constants: worth sharing), pending candidates take their reachability test
+// when sc.lane_acc_batch wait -- or, both, when nothing else can move.  Same rays, same results as bvh_lanes.
+template <bool ANY>
+__device__ __forceinline__ void bvh_lanes_step(const DevSceneView& sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                                               const float* __restrict__ tmax, int64_t n, float eps_f,
+                                               rt_hit* __restrict__ out, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order) {
+    const int lane = threadIdx.x & 63;
+    const int nn = sc.nbvh;
+    const bool use_tmax = tmax != nullptr;
+    bool have = false, more = true, occ = false, fresh = false;
+    int64_t idx = 0;
+    BvhLaneWalk wk; wk.i = nn; wk.far_limit = 0.f; wk.nodes = sc.bvh_oct[0];
+    wk.r = Rayf{0, 0, 0, 0, 0, 1};
+    wk.bc = BvhConsts{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    LaneCursor cu; lane_cursor_reset(cu);
+    Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+    int cur = (int)(blockIdx.x & 7u), spent = 0;                    // claims by XCD range, as in bvh_lanes
+    int64_t pool_next = 0, pool_end = 0, left_seen = n >> 3;
+    for (;;) {
+        if (have && !lane_walk_busy(wk, cu, nn)) {                  // this lane's walk is over: its result, and the lane is free
+            if (ANY) occluded[idx] = occ ? 1 : 0;
+            else {
+                float* o = reinterpret_cast<float*>(out + idx);
+                reinterpret_cast<int32_t*>(o)[0] = best.prim;
+                o[1] = best.len; o[2] = best.px; o[3] = best.py; o[4] = best.pz;
+            }
+            have = false;
+        }
+        const unsigned long long need = rt_ballot(!have && more);
+        unsigned long long busy = rt_ballot(have);
+        if (need != 0ull && (busy == 0ull || __builtin_popcountll(need) >= sc.lane_refill_batch)) {
+            // The wave's pool of claimed rays [pool_next, pool_end): ONE atomic per chunk, not per refill -- a device-scope
+            // atomic on a word that thousands of waves share is the slowest thing this kernel does.  Chunks shrink as the
+            // range runs out (guided: a share of what was left at the wave's last claim), so no wave sits on a long
+            // private queue while the others are done.
+            while (pool_next >= pool_end && more) {
+                const int64_t lo = (n * cur) >> 3, hi = (n * (cur + 1)) >> 3;
+                int64_t want = left_seen / (int64_t)(gridDim.x >> 2 ? gridDim.x >> 2 : 1);      // ~ 1/2 of a fair share of the range's rest (1/8 of the waves start in it)
+                want = want < 16 ? 16 : (want > sc.lane_chunk ? sc.lane_chunk : want);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(sc.ray_counter + cur, (unsigned long long)want);
+                base = __shfl(base, 0, 64);
+                if ((int64_t)base >= hi - lo) {                     // this range is used up (wave-uniform): the next one
+                    cur = (cur + 1) & 7;
+                    if (++spent == 8) more = false;
+                    left_seen = n >> 3;
+                } else {
+                    pool_next = lo + (int64_t)base;
+                    pool_end = pool_next + want < hi ? pool_next + want : hi;
+                    left_seen = hi - pool_end;
+                }
+            }
+            if (!have && more) {
+                const int64_t claim = pool_next + __builtin_popcountll(need & ((1ull << lane) - 1ull));
+                const int64_t my = (claim < pool_end && order != nullptr) ? (int64_t)order[claim] : claim;
+                if (claim >= pool_end) { }                          // the pool ran out: claim again next time round
+                else if (active != nullptr && active[my] < 0) {
+                    if (ANY) occluded[my] = 0;
+                    else {
+                        float* o = reinterpret_cast<float*>(out + my);
+                        reinterpret_cast<int32_t*>(o)[0] = -1; o[1] = 1e9f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f;
+                    }
+                } else {
+                    const Rayf r = load_ray(rays, my);
+                    const RayAux aux = ray_aux(r);
+                    if (bvh_fit(aux)) {
+                        idx = my; have = true; occ = false; fresh = true;
+                        best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+                        bvh_lane_start(sc, r, aux, ANY ? (use_tmax ? tmax[my] : 1e9f) : 0.f, wk);
+                        lane_cursor_reset(cu);
+                    }
+                }
+            }
+            if (more) { const int64_t took = pool_next + __builtin_popcountll(need); pool_next = took < pool_end ? took : pool_end; }
+            if (sc.nloose > 0 && rt_ballot(fresh) != 0ull) {        // primitives outside the trees, for the rays just taken (bvh_lanes says why first)
+                loose_prims<ANY>(sc, wk.r, fresh, eps_f, wk.far_limit, use_tmax, best, occ);
+                if (ANY && fresh && occ) lane_walk_end(wk, cu, nn);
+            }
+            fresh = false;
+            busy = rt_ballot(have);
+        }
+        if (busy == 0ull) { if (rt_ballot(more) == 0ull) break; continue; }
+        const unsigned long long pend = rt_ballot(have && cu.acc >= 0);
+        const unsigned long long stepping = rt_ballot(have && cu.acc < 0 && lane_walk_busy(wk, cu, nn));
+        const bool do_acc = pend != 0ull && (stepping == 0ull || __builtin_popcountll(pend) >= sc.lane_acc_batch);
+        bvh_lane_step(sc, wk, cu, have && lane_walk_busy(wk, cu, nn), ANY, eps_f, use_tmax, do_acc, best, occ);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_trace_closest_bvh_step(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                         int64_t n, float eps_f, rt_hit* __restrict__ out, const int32_t* __restrict__ order) {
+    bvh_lanes_step<false>(sc, rays, active, nullptr, n, eps_f, out, nullptr, order);
+}
+
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_trace_any_bvh_step(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
+                     const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order) {
+    bvh_lanes_step<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded, order);
+}
+
 // the build's own hierarchy instead of the reference's tree (trace_device.h: traverse_bvh)
 extern "C" __global__ void __launch_bounds__(256)
 k_trace_closest_bvh(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
@@ -459,7 +563,8 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
+            if (sc.lane_step) hipLaunchKernelGGL(k_trace_closest_bvh_step, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
+            else hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
         }
         hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, lanes, d_out);
         return hipGetLastError();
@@ -481,7 +586,8 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
+            if (sc.lane_step) hipLaunchKernelGGL(k_trace_any_bvh_step, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
+            else hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
         }
         hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, lanes, d_occ);
         return hipGetLastError();

@@ -91,6 +91,11 @@ struct DevBvhNode32 {
 static_assert(sizeof(DevBvhNode32) == 32, "DevBvhNode32 must be 32 bytes");
 struct DevRefLeaf { int32_t leaf; int32_t rank; };   // a reference leaf (index in layout 7) holding a triangle, and the
                                                      // reference's visit rank of that record
+// reachable_rank's first probe for BVH triangle t in ONE record (made on the device by k_tri_reach from bvh_tri_ref,
+// bvh_ref_leaf and ref_chain_box): the chain box of the first reference leaf holding t and that record's visit rank.
+// lo[0] = NaN: no chain box (or no leaf): the caller takes reachable_rank itself.
+struct DevTriReach { float lo[3]; float hi[3]; int32_t rank; int32_t pad; };
+static_assert(sizeof(DevTriReach) == 32, "DevTriReach must be 32 bytes");
 
 struct DevLoose {           // 48 B: a primitive tested one by one after the trees
     float a[9];             // triangle: v0,e1,e2   sphere: center(3), radius, unused
@@ -156,6 +161,11 @@ struct DevSceneView {       // passed by value to kernels
     int32_t lane_layout_mask;           // per-lane walks use layout (octant & mask): 0 = one layout for all (default), 7 = the ray's own octant
     const DevLeafTri* bvh_tris;         // every tree triangle once; .rank = its index t into bvh_tri_ref
     const int32_t* bvh_tri_ref;         // [t][2]: first, count into bvh_ref_leaf
+    const DevTriReach* bvh_tri_reach;   // [t]: the first probe of reachable_rank in one record (single-step per-lane walk)
+    int32_t lane_step;                  // per-lane walks one record at a time (trace_device.h: bvh_lane_step); needs bvh_c32 and bvh_tri_reach
+    int32_t lane_refill_batch;          // ... idle lanes claim new rays when this many wait (or no lane walks)
+    int32_t lane_chunk;                 // ... a wave claims at most this many rays with one atomic
+    int32_t lane_acc_batch;             // ... pending candidates take their reachability test when this many wait (or no lane can step)
     const DevRefLeaf* bvh_ref_leaf;     // the reference leaves holding triangle t, by rising rank
     const int32_t* ref_parent;          // parent of reference node i (layout 7), -1 = a root
     const float* ref_chain_box;         // [node][6]: lo, hi of the intersection of the boxes on node i's chain (NaN lo[0]: none)
@@ -255,6 +265,7 @@ hipError_t rtk_next_ray_counter(DevSceneView& sc, hipStream_t st);
 // kernels_build.hip: the other seven octant layouts of the reference trees (from layout 7) and of the BVH (from layout 0)
 hipError_t rtk_kd_layouts(const DevNode* src, int32_t n, const int32_t* d_roots, int32_t nroots, DevNode* const dst[7], hipStream_t st);
 hipError_t rtk_bvh_layouts(const DevBvhNode* src, int32_t n, DevBvhNode* const dst[8], hipStream_t st);
+hipError_t rtk_tri_reach(const int32_t* tri_ref, const DevRefLeaf* ref_leaf, const float* chain_box, int64_t nt, DevTriReach* out, hipStream_t st);
 // kernels_paths.hip: the rays of a queue with their whole subtrees of the recursion, one weighted sum per queue entry
 int rtk_paths_max_lights();
 size_t rtk_paths_stack_bytes(int64_t n, int depth0, int max_depth);

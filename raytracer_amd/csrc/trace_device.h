@@ -831,6 +831,121 @@ __device__ __forceinline__ bool bvh_lane_leaf(const DevSceneView& sc, BvhLaneWal
     return bvh_lane_leaf_any(sc, wk, t0, t1, eps_f, use_tmax, ANY, best);
 }
 
+// ---------------------------------------------------------------------------
+// The per-lane walk ONE RECORD AT A TIME (round 3; DESIGN 4.1c "single-step walk").  The while-while shape above makes a
+// wave wait for its slowest lane twice over: a lane that has found its next leaf idles until the last lane of the wave
+// has found one too (the mean lane needs 24 node steps to its next leaf, the slowest of 64 about 100: measured 13 of 64
+// lanes active per vector instruction), and every such wave step is one dependent fetch -- the kernel is bound by the
+// latency of a fetch that only a fifth of its lanes have issued.  Here every lane with a ray fetches exactly ONE record
+// per wave step, whichever its own walk needs next -- a node, a triangle of its current leaf, or the reachability
+// record of a candidate hit -- through one address select and one set of loads, so a wave step carries up to 64 fetches
+// and a ray advances at every step.  The records a ray sees, their order, every test and the accept rule are those of
+// bvh_lane_next_leaf_c32 + bvh_lane_leaf_any: the same hit, bit for bit.
+//   A candidate (a triangle that passed the exact test) waits in the cursor until the caller lets the pending lanes
+// run the reachability test together (`do_acc`): reachable_rank's first probe is one 32-byte record (DevTriReach, made
+// on the device by k_tri_reach from the tables reachable_rank reads); the rare ray that misses it takes the original
+// function.  best / the far limit do not change while a candidate waits, so deferring it changes nothing.
+struct LaneCursor {
+    int ti, t1;            // the triangles of the current leaf still to test: [ti, t1)
+    int acc;               // >= 0: a candidate hit waits for its reachability test (the triangle's index into bvh_tri_reach)
+    float clen, cpx, cpy, cpz; int cprim;
+};
+__device__ __forceinline__ void lane_cursor_reset(LaneCursor& cu) { cu.ti = cu.t1 = 0; cu.acc = -1; cu.clen = cu.cpx = cu.cpy = cu.cpz = 0.f; cu.cprim = -1; }
+__device__ __forceinline__ bool lane_walk_busy(const BvhLaneWalk& wk, const LaneCursor& cu, int nn) { return wk.i < nn || cu.ti < cu.t1 || cu.acc >= 0; }
+__device__ __forceinline__ void lane_walk_end(BvhLaneWalk& wk, LaneCursor& cu, int nn) { wk.i = nn; cu.ti = cu.t1 = 0; cu.acc = -1; }
+
+// one step for every lane that is `on` (a lane whose walk is over must pass on = false).  any: the lane's walk is an
+// any-hit walk (returns with occ = true and the walk ended when a reachable hit below wk.far_limit is found).
+__device__ __forceinline__ void bvh_lane_step(const DevSceneView& sc, BvhLaneWalk& wk, LaneCursor& cu, bool on, const bool any, float eps_f,
+                                              bool use_tmax, bool do_acc, Closest& best, bool& occ,
+                                              unsigned* nbox = nullptr, unsigned* ntri = nullptr) {
+    const int nn = sc.nbvh;
+    const bool k_acc = on && cu.acc >= 0;
+    const bool k_tri = on && cu.acc < 0 && cu.ti < cu.t1;
+    const bool k_node = on && cu.acc < 0 && cu.ti >= cu.t1 && wk.i < nn;
+    // one address, one set of loads: 32 bytes of a node or a reachability record, 48 of a triangle
+    const char* p = (const char*)sc.bvh_c32 + (k_node ? ((size_t)(unsigned)wk.i << 5) : (size_t)0);
+    if (k_tri) p = (const char*)sc.bvh_tris + (size_t)(unsigned)cu.ti * sizeof(DevLeafTri);
+    if (k_acc) p = (const char*)sc.bvh_tri_reach + ((size_t)(unsigned)cu.acc << 5);
+    const bool k_accgo = k_acc && do_acc;
+    float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
+    if (k_node || k_tri || k_accgo) { q0 = reinterpret_cast<const float4*>(p)[0]; q1 = reinterpret_cast<const float4*>(p)[1]; }   // (a lane without a fetch asks the texture path for nothing)
+    if (k_tri) q2 = reinterpret_cast<const float4*>(p)[2];
+    const Rayf& r = wk.r;
+    if (k_node) {                                                           // bvh_lane_next_leaf_c32_lim, one trip
+        const BvhConsts& b = wk.bc;
+        const float limit = any ? wk.far_limit : best.len;
+        const unsigned link = (unsigned)__float_as_int(q1.z), sq = (unsigned)__float_as_int(q1.w);
+        const float slack = __int_as_float((int)((sq >> 18) << 17)), srho = __int_as_float((int)(((sq >> 4) & 0x3fffu) << 17));
+        const float sl = __builtin_fmaf(slack, b.d0, srho) + b.sl0;
+        const rt_v2f s2 = {-sl, sl};
+        rt_v2f x = {q0.x, q0.y}, y = {q0.z, q0.w}, z = {q1.x, q1.y};
+        x = x + s2; y = y + s2; z = z + s2;
+        x.x = __builtin_fmaf(x.x, b.rx, b.px); x.y = __builtin_fmaf(x.y, b.rx, b.px);
+        y.x = __builtin_fmaf(y.x, b.ry, b.py); y.y = __builtin_fmaf(y.y, b.ry, b.py);
+        z.x = __builtin_fmaf(z.x, b.rz, b.pz); z.y = __builtin_fmaf(z.y, b.rz, b.pz);
+        const float en = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
+        const float ex = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
+        const bool hit = !(ex < en || ex < 0.0f || en * b.dlen > limit);
+        const bool leaf = (link >> 31) != 0;
+        if (nbox) *nbox += 1;
+        wk.i = (hit || leaf) ? wk.i + 1 : (int)link;
+        if (hit && leaf) { cu.ti = (int)(link & 0x7fffffffu); cu.t1 = cu.ti + (int)((sq >> 1) & 7u); }
+    }
+    if (k_tri) {                                                            // bvh_lane_leaf_any, one triangle
+        cu.ti += 1;
+        const int flags = __float_as_int(q2.z);
+        do {
+            if (any && use_tmax && (flags & RT_PF_SKIP_SHADOW)) break;
+            if (ntri) *ntri += 1;
+            const float e1x = q0.w, e1y = q1.x, e1z = q1.y;
+            const float e2x = q1.z, e2y = q1.w, e2z = q2.x;
+            const float pvx = r.dy * e2z - r.dz * e2y;
+            const float pvy = r.dz * e2x - r.dx * e2z;
+            const float pvz = r.dx * e2y - r.dy * e2x;
+            const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+            if (__builtin_fabsf(det) < eps_f) break;
+            const float ri = __builtin_amdgcn_rcpf(det);
+            const float tx = r.ox - q0.x, ty = r.oy - q0.y, tz = r.oz - q0.z;
+            const float du = tx * pvx + ty * pvy + tz * pvz;
+            const float ua = du * ri;
+            if ((ua < -1e-30f) || (ua > 1.00001f)) break;
+            const float qx = ty * e1z - tz * e1y;
+            const float qy = tz * e1x - tx * e1z;
+            const float qz = tx * e1y - ty * e1x;
+            const float dv = r.dx * qx + r.dy * qy + r.dz * qz;
+            const float dt = e2x * qx + e2y * qy + e2z * qz;
+            const float va = dv * ri, ta = dt * ri;
+            if ((va < -1e-30f) || (ua + va > 1.00002f) || (ta < -1e-30f)) break;
+            const float detInv = 1.0f / det;                                     // hw4.cpp:211-230, exactly
+            const float u = du * detInv;
+            if (u < 0 || u > 1.0f) break;
+            const float v = dv * detInv;
+            if (v < 0 || u + v > 1.0f) break;
+            const float tt = dt * detInv;
+            if (tt < 0) break;
+            const float px = r.ox + tt * r.dx, py = r.oy + tt * r.dy, pz = r.oz + tt * r.dz;
+            const float len = dist_to(r, px, py, pz);
+            const int prim = __float_as_int(q2.y);
+            if (any) { if (!(len < wk.far_limit && len >= sc.tol_f)) break; }
+            else if (!(len <= best.len && len >= sc.tol_f && (!sc.culling || facing(sc, prim, false, r, px, py, pz)))) break;
+            cu.acc = __float_as_int(q2.w); cu.clen = len; cu.cpx = px; cu.cpy = py; cu.cpz = pz; cu.cprim = prim;
+        } while (false);
+    }
+    if (k_accgo) {                                                          // reachable_rank, first probe from one record
+        const float lo[3] = {q0.x, q0.y, q0.z}, hi[3] = {q0.w, q1.x, q1.y};
+        int rr = __float_as_int(q1.z);
+        if (!(lo[0] == lo[0] && box_test_b(lo, hi, r))) rr = reachable_rank(sc, cu.acc, r);
+        cu.acc = -1;
+        if (rr != 0x7fffffff) {
+            if (any) { occ = true; lane_walk_end(wk, cu, nn); }
+            else if (cu.clen < best.len || rr < best.rank) {
+                best.len = cu.clen; best.prim = cu.cprim; best.px = cu.cpx; best.py = cu.cpy; best.pz = cu.cpz; best.rank = rr;
+            }
+        }
+    }
+}
+
 // primitives outside every tree, in index order (the whole scene for final.cpp)
 template <bool ANY, bool COUNT = false>
 __device__ __forceinline__ void loose_prims(const DevSceneView& sc, const Rayf& r, bool valid,
