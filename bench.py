@@ -543,9 +543,12 @@ def drt_analysis(torch, gs, sd, cam, p, sp, with_cpu=True):
     abi.check(gs.L.rt_scene_set_option(gs.h, abi.RT_OPT_RENDER_OVERLAP, 1))
     stw = render_work(gs, cam, p, sp, torch)
     # the frame's traversal time by kernel family; the roofline goes to the largest
+    # (the per-lane pass kernels are the single-step ones unless RT_LANE_STEP=0 asks for the while-while walk)
+    lane_k = ("k_trace_closest_bvh_lanes", "k_trace_any_bvh_lanes") if os.environ.get("RT_LANE_STEP", "1") == "0" else \
+             ("k_trace_closest_bvh_step", "k_trace_any_bvh_step")
     fam = {
-        "k_trace_closest_bvh_lanes": (st.lane_closest_ms, st.lane_closest_launches, st.lane_closest_rays, stw.lane_closest_work, 20),
-        "k_trace_any_bvh_lanes": (st.lane_any_ms, st.lane_any_launches, st.lane_any_rays, stw.lane_any_work, 1),
+        lane_k[0]: (st.lane_closest_ms, st.lane_closest_launches, st.lane_closest_rays, stw.lane_closest_work, 20),
+        lane_k[1]: (st.lane_any_ms, st.lane_any_launches, st.lane_any_rays, stw.lane_any_work, 1),
         "k_trace_closest_bvh": (st.trace_closest_ms - st.lane_closest_ms, st.trace_closest_launches - st.lane_closest_launches,
                                 st.rays_primary + st.rays_reflect + st.rays_refract - st.lane_closest_rays,
                                 [a - b for a, b in zip(stw.closest_work, stw.lane_closest_work)], 20),
@@ -563,7 +566,7 @@ def drt_analysis(torch, gs, sd, cam, p, sp, with_cpu=True):
     ms, launches, krays, work, ob = fam[kernel]
     launches = max(1, launches)
     alg, wave = traversal_bytes(work, krays, out_bytes=ob)
-    per_lane = kernel.endswith("_lanes")
+    per_lane = kernel.endswith("_lanes") or kernel.endswith("_step")
     rf = make_roofline("drt_1m", kernel, ms / launches, krays / launches, alg / launches,
                        (alg if per_lane else wave) / launches,     # per-lane kernels: every lane fetches its own records
                        launches_per_frame=launches, ms_per_frame_in_this_kernel=ms, frame_ms_on_one_stream=one_stream_ms,

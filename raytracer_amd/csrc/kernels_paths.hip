@@ -45,11 +45,12 @@ struct PathArgs {
                                          // children; [5] closest-hit rays, [6] shadow rays of THIS kernel
     unsigned long long* work;            // COUNT: [0] box tests, [1] triangle records of the closest walks; [4], [5] of the shadow walks
     int32_t batch;                       // events run when this many lanes wait (or no lane walks)
+    const int32_t* order;                // NULL, or the order in which queue entries are handed to lanes (rtk_ray_order); sums go to the entries' own slots
 };
 
 enum PathMode { M_IDLE = 0, M_CLOSEST, M_SHADOW, M_SHADOW_SETUP, M_SHADE, M_NEXT, M_START };
 
-template <bool COUNT>
+template <bool COUNT, bool STEP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
     const int lane = threadIdx.x & 63;
@@ -68,6 +69,7 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
     wk.bc = BvhConsts{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
     bool occ = false;
+    LaneCursor cu; lane_cursor_reset(cu);         // the single-step walk's cursor (trace_device.h: bvh_lane_step); idle in the while-while walk
     // the hit being shaded (alive from the end of the closest walk to the children)
     HitCtx c; c.ox = c.oy = c.oz = 0.f; c.dx = c.dy = 0.f; c.dz = 1.f; c.hx = c.hy = c.hz = 0.f; c.nx = c.ny = 0.f; c.nz = 1.f; c.prim = -1; c.mat = 0;
     int light = 0; unsigned occbits = 0u;
@@ -75,20 +77,23 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
     PathStackEntry* const stk = a.stack + (size_t)blockIdx.x * (size_t)a.stack_depth * 64 + lane;     // entry s at stk[64 s]
     unsigned n_rays = 0, n_hits = 0, n_refl = 0, n_refr = 0, n_shadow = 0;
     unsigned wb_c = 0, wt_c = 0, wb_s = 0, wt_s = 0;
+    unsigned d_iter = 0, d_on = 0, d_ev = 0, d_wait = 0;       // COUNT: wave steps, lanes that stepped, events, lanes waiting at events (lane 0 / per lane)
     // claims: eight contiguous ranges of the queue with a counter each, a wave starts in the range of its workgroup's XCD
-    // label and moves on when its own is used up (kernels_trace.hip: bvh_lanes)
-    int cur = (int)(blockIdx.x & 7u), spent = 0;
+    // label and moves on when its own is used up; one atomic per chunk of entries (trace_device.h: RayPool)
+    RayPool pool; ray_pool_init(pool, a.n);
 
     for (;;) {
         const bool in_walk = mode == M_CLOSEST || mode == M_SHADOW;
-        const bool walking = in_walk && wk.i < nn;
-        const bool waiting = (in_walk && wk.i >= nn) || (mode == M_IDLE && more);
+        const bool walk_on = lane_walk_busy(wk, cu, nn);
+        const bool walking = in_walk && walk_on;
+        const bool waiting = (in_walk && !walk_on) || (mode == M_IDLE && more);
         const unsigned long long wm = rt_ballot(waiting), km = rt_ballot(walking);
         if ((wm | km) == 0ull) break;
         if (wm != 0ull && (km == 0ull || __builtin_popcountll(wm) >= a.batch)) {
+            if (COUNT) { d_ev += 1; d_wait += waiting ? 1u : 0u; }
             // ---- events, in the order a ray moves through them ----------------------------------------------------
             // A: a closest-hit walk has ended (hw4.cpp:873-895)
-            if (mode == M_CLOSEST && wk.i >= nn) {
+            if (mode == M_CLOSEST && !walk_on) {
                 if (best.prim < 0) mode = M_NEXT;
                 else {
                     ++n_hits;
@@ -98,7 +103,7 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                     light = 0; occbits = 0u;
                     mode = L > 0 ? M_SHADOW_SETUP : M_SHADE;
                 }
-            } else if (mode == M_SHADOW && wk.i >= nn) {
+            } else if (mode == M_SHADOW && !walk_on) {
                 // B: a shadow walk has ended (hw4.cpp:929-931)
                 occbits |= (occ ? 1u : 0u) << light;
                 ++light;
@@ -154,21 +159,13 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
             }
             // E: idle lanes claim queue entries
             {
-                unsigned long long need = rt_ballot(mode == M_IDLE && more);
-                while (need != 0ull) {
-                    const int first = __builtin_ctzll(need);
-                    const int64_t lo = (a.n * cur) >> 3, hi = (a.n * (cur + 1)) >> 3;
-                    unsigned long long base = 0;
-                    if (lane == first) base = atomicAdd(sc.ray_counter + cur, (unsigned long long)__builtin_popcountll(need));
-                    base = __shfl(base, first, 64);
-                    if ((int64_t)base >= hi - lo) {                     // this range is used up (wave-uniform): the next one
-                        cur = (cur + 1) & 7;
-                        if (++spent == 8) { more = false; break; }
-                        continue;
-                    }
-                    if (mode == M_IDLE) {
-                        const int64_t my = lo + (int64_t)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
-                        if (my < hi) {                                  // (beyond the range: claims again at the next events)
+                const unsigned long long need = rt_ballot(mode == M_IDLE && more);
+                if (need != 0ull) {
+                    if (!ray_pool_fill(sc, pool, a.n, lane)) more = false;
+                    else {
+                        const int64_t claim = ray_pool_take(pool, need, lane);  // (-1: the pool ran out -- claims again at the next events)
+                        const int64_t my = (claim >= 0 && a.order != nullptr) ? (int64_t)a.order[claim] : claim;
+                        if (my >= 0) {
                             const int p = a.pix[my];
                             if (p < 0) { a.contrib[3 * my] = 0.f; a.contrib[3 * my + 1] = 0.f; a.contrib[3 * my + 2] = 0.f; }
                             else {
@@ -180,7 +177,6 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                             }
                         }
                     }
-                    break;
                 }
             }
             // F, G: set a walk up -- the ray at hand (closest hit), or the shadow ray towards light `light`
@@ -198,6 +194,7 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                 const RayAux aux = ray_aux(wk.r);
                 fresh = true; occ = false;
                 best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
+                lane_cursor_reset(cu);
                 if (bvh_fit(aux)) bvh_lane_start(sc, wk.r, aux, shadow ? 1e9f : 0.f, wk);      // HW4's IsInShadow has no far limit (Q4)
                 else { unfit = true; wk.i = nn; wk.far_limit = shadow ? 1e9f : 0.f; }
                 mode = shadow ? M_SHADOW : M_CLOSEST;
@@ -215,14 +212,25 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                 loose_prims<false>(sc, wk.r, fresh && mode == M_CLOSEST, a.eps_f, 0.f, false, best, o2);
                 Closest dummy; dummy.len = 1e9f; dummy.prim = -1; dummy.px = dummy.py = dummy.pz = 0.f; dummy.rank = 0x7fffffff;
                 loose_prims<true>(sc, wk.r, fresh && mode == M_SHADOW, a.eps_f, 0.f, false, dummy, occ);
-                if (mode == M_SHADOW && occ) wk.i = nn;                 // occluded already: nothing to walk
+                if (mode == M_SHADOW && occ) lane_walk_end(wk, cu, nn); // occluded already: nothing to walk
             }
         }
         // ---- one walk step for every lane inside a walk -----------------------------------------------------------
         {
             const bool any = mode == M_SHADOW;
-            const bool on = (mode == M_CLOSEST || any) && wk.i < nn;
-            if (rt_ballot(on) != 0ull) {
+            const bool on = (mode == M_CLOSEST || any) && lane_walk_busy(wk, cu, nn);
+            if (STEP) {
+                // one record for every walking lane; candidates take their reachability test when enough of them wait or
+                // no lane can step (kernels_trace.hip: bvh_lanes_step)
+                const unsigned long long pend = rt_ballot(on && cu.acc >= 0), stepping = rt_ballot(on && cu.acc < 0);
+                if ((pend | stepping) != 0ull) {
+                    const bool do_acc = pend != 0ull && (stepping == 0ull || __builtin_popcountll(pend) >= sc.lane_acc_batch);
+                    unsigned nb = 0, nt = 0;
+                    if (COUNT) { d_iter += 1; d_on += (on && (cu.acc < 0 || do_acc)) ? 1u : 0u; }
+                    bvh_lane_step(sc, wk, cu, on, any, a.eps_f, false, do_acc, best, occ, COUNT ? &nb : nullptr, COUNT ? &nt : nullptr);
+                    if (COUNT) { if (any) { wb_s += nb; wt_s += nt; } else { wb_c += nb; wt_c += nt; } }
+                }
+            } else if (rt_ballot(on) != 0ull) {
                 const float limit = any ? wk.far_limit : best.len;
                 int t0, t1;
                 unsigned nb = 0, nt = 0;
@@ -245,10 +253,10 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
             if (lane == 0 && x) { atomicAdd(a.counters + slot[k], x); if (k == 0) atomicAdd(a.counters + 5, x); }
         }
         if (COUNT) {
-            unsigned q[4] = {wb_c, wt_c, wb_s, wt_s};
-            const int ws[4] = {0, 1, 4, 5};
+            unsigned q[8] = {wb_c, wt_c, wb_s, wt_s, lane == 0 ? d_iter : 0u, d_on, lane == 0 ? d_ev : 0u, d_wait};
+            const int ws[8] = {0, 1, 4, 5, 2, 3, 6, 7};     // [2], [3], [6], [7]: diagnostics (render.cpp: RT_PATH_DIAG)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 unsigned long long x = q[k];
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
@@ -277,7 +285,7 @@ size_t rtk_paths_stack_bytes(int64_t n, int depth0, int max_depth) {
 hipError_t rtk_paths(const DevSceneView& sc0, const rt_ray* rays, const int32_t* pix, const float* w, const float* nr,
                      const uint32_t* code, int64_t n, int depth0, int max_depth, float eps_f, float ambient, const float eye[3],
                      float start_nr, uint64_t seed, float light_radius, float glossy, float* contrib, void* stack,
-                     unsigned long long* counters, unsigned long long* work, hipStream_t st) {
+                     unsigned long long* counters, unsigned long long* work, hipStream_t st, const int32_t* order) {
     if (n <= 0) return hipSuccess;
     DevSceneView sc = sc0;
     hipError_t e = rtk_next_ray_counter(sc, st);         // this launch's eight range counters, zeroed on `st`
@@ -288,9 +296,14 @@ hipError_t rtk_paths(const DevSceneView& sc0, const rt_ray* rays, const int32_t*
     a.eps_f = eps_f; a.ambient = ambient; a.eye[0] = eye[0]; a.eye[1] = eye[1]; a.eye[2] = eye[2]; a.start_nr = start_nr;
     a.seed = seed; a.light_radius = light_radius; a.glossy = glossy; a.contrib = contrib;
     a.stack = (PathStackEntry*)stack; a.stack_depth = (max_depth - depth0 + 1) > 1 ? (max_depth - depth0 + 1) : 1;
-    a.counters = counters; a.work = work; a.batch = batch;
+    a.counters = counters; a.work = work; a.batch = batch; a.order = order;
     const unsigned grid = (unsigned)paths_waves(n);
-    if (work) hipLaunchKernelGGL(k_paths_bvh_lanes<true>, dim3(grid), dim3(64), 0, st, sc, a);
-    else hipLaunchKernelGGL(k_paths_bvh_lanes<false>, dim3(grid), dim3(64), 0, st, sc, a);
+    if (sc.lane_step) {
+        if (work) hipLaunchKernelGGL((k_paths_bvh_lanes<true, true>), dim3(grid), dim3(64), 0, st, sc, a);
+        else hipLaunchKernelGGL((k_paths_bvh_lanes<false, true>), dim3(grid), dim3(64), 0, st, sc, a);
+    } else {
+        if (work) hipLaunchKernelGGL((k_paths_bvh_lanes<true, false>), dim3(grid), dim3(64), 0, st, sc, a);
+        else hipLaunchKernelGGL((k_paths_bvh_lanes<false, false>), dim3(grid), dim3(64), 0, st, sc, a);
+    }
     return hipGetLastError();
 }

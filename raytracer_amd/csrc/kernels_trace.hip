@@ -216,8 +216,7 @@ __device__ __forceinline__ void bvh_lanes_step(const DevSceneView& sc, const rt_
     wk.bc = BvhConsts{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     LaneCursor cu; lane_cursor_reset(cu);
     Closest best; best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
-    int cur = (int)(blockIdx.x & 7u), spent = 0;                    // claims by XCD range, as in bvh_lanes
-    int64_t pool_next = 0, pool_end = 0, left_seen = n >> 3;
+    RayPool pool; ray_pool_init(pool, n);
     for (;;) {
         if (have && !lane_walk_busy(wk, cu, nn)) {                  // this lane's walk is over: its result, and the lane is free
             if (ANY) occluded[idx] = occ ? 1 : 0;
@@ -231,31 +230,11 @@ __device__ __forceinline__ void bvh_lanes_step(const DevSceneView& sc, const rt_
         const unsigned long long need = rt_ballot(!have && more);
         unsigned long long busy = rt_ballot(have);
         if (need != 0ull && (busy == 0ull || __builtin_popcountll(need) >= sc.lane_refill_batch)) {
-            // The wave's pool of claimed rays [pool_next, pool_end): ONE atomic per chunk, not per refill -- a device-scope
-            // atomic on a word that thousands of waves share is the slowest thing this kernel does.  Chunks shrink as the
-            // range runs out (guided: a share of what was left at the wave's last claim), so no wave sits on a long
-            // private queue while the others are done.
-            while (pool_next >= pool_end && more) {
-                const int64_t lo = (n * cur) >> 3, hi = (n * (cur + 1)) >> 3;
-                int64_t want = left_seen / (int64_t)(gridDim.x >> 2 ? gridDim.x >> 2 : 1);      // ~ 1/2 of a fair share of the range's rest (1/8 of the waves start in it)
-                want = want < 16 ? 16 : (want > sc.lane_chunk ? sc.lane_chunk : want);
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(sc.ray_counter + cur, (unsigned long long)want);
-                base = __shfl(base, 0, 64);
-                if ((int64_t)base >= hi - lo) {                     // this range is used up (wave-uniform): the next one
-                    cur = (cur + 1) & 7;
-                    if (++spent == 8) more = false;
-                    left_seen = n >> 3;
-                } else {
-                    pool_next = lo + (int64_t)base;
-                    pool_end = pool_next + want < hi ? pool_next + want : hi;
-                    left_seen = hi - pool_end;
-                }
-            }
-            if (!have && more) {
-                const int64_t claim = pool_next + __builtin_popcountll(need & ((1ull << lane) - 1ull));
-                const int64_t my = (claim < pool_end && order != nullptr) ? (int64_t)order[claim] : claim;
-                if (claim >= pool_end) { }                          // the pool ran out: claim again next time round
+            if (!ray_pool_fill(sc, pool, n, lane)) more = false;   // (trace_device.h: RayPool -- one atomic per chunk of rays)
+            if (more) {
+                const int64_t claim = ray_pool_take(pool, need, lane);
+                const int64_t my = (claim >= 0 && order != nullptr) ? (int64_t)order[claim] : claim;
+                if (claim < 0) { }                                  // not asking, or the pool ran out: claim again next time round
                 else if (active != nullptr && active[my] < 0) {
                     if (ANY) occluded[my] = 0;
                     else {
@@ -273,7 +252,6 @@ __device__ __forceinline__ void bvh_lanes_step(const DevSceneView& sc, const rt_
                     }
                 }
             }
-            if (more) { const int64_t took = pool_next + __builtin_popcountll(need); pool_next = took < pool_end ? took : pool_end; }
             if (sc.nloose > 0 && rt_ballot(fresh) != 0ull) {        // primitives outside the trees, for the rays just taken (bvh_lanes says why first)
                 loose_prims<ANY>(sc, wk.r, fresh, eps_f, wk.far_limit, use_tmax, best, occ);
                 if (ANY && fresh && occ) lane_walk_end(wk, cu, nn);

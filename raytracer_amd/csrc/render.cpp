@@ -209,7 +209,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         // rank's share of that frame at 8 ranks: 0.97 M entries, passes 10.3 ms, path kernel 9.9 ms and no per-depth round trips
         // (frame 20.5 -> 16.5 ms).  RT_PATH_MAX_ROOTS overrides the threshold.
         // The choice is made once, at the option's depth (deeper queues are always smaller).
-        static const int64_t path_max_roots = [] { const char* e = getenv("RT_PATH_MAX_ROOTS"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)3000000; }();
+        static const int64_t path_max_roots = [] { const char* e = getenv("RT_PATH_MAX_ROOTS"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)16000000; }();
         if (use_paths && depth == s->path_depth && n <= path_max_roots) {
             void *pc, *stk;
             RTCHK(s->scratch(S_PATH_CONTRIB, (size_t)n * 12, &pc));
@@ -217,8 +217,16 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             ++passes; pass_n.push_back(n); pass_lane.push_back(2); path_roots += n;
             if (order_done) { HIPCHK(hipStreamWaitEvent(st, order_done, 0), "hipStreamWaitEvent"); order_done = nullptr; }
             RTCHK(mark(st));
+            // RT_PATH_SORT=1 (experiment): the entries are handed out in the order of their origins' cells, so the range an XCD
+            // claims from is one region of the scene
+            static const bool path_sort = [] { const char* e = getenv("RT_PATH_SORT"); return e && atoi(e) != 0; }();
+            const int32_t* order_p = nullptr;
+            if (path_sort) {
+                void* ow; RTCHK(s->scratch(S_ORDER_C, rtk_ray_order_workspace(n), &ow));
+                HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_p, st), "ray order");
+            }
             HIPCHK(rtk_paths(view, q_rays, q_pix, q_w, q_nr, q_code, n, depth, p->max_depth, s->eps_f, p->ambient_intensity, cam->center,
-                             p->start_nr, p->seed, p->light_radius, p->glossy, (float*)pc, stk, d_ctr, d_work ? d_work + 16 : nullptr, st),
+                             p->start_nr, p->seed, p->light_radius, p->glossy, (float*)pc, stk, d_ctr, d_work ? d_work + 16 : nullptr, st, order_p),
                    "k_paths_bvh_lanes");
             RTCHK(mark(st)); RTCHK(mark(st)); RTCHK(mark(st));
             // the entries' sums join the pixels after every earlier pass's (the accumulation stream keeps pass order)
@@ -373,9 +381,13 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         stats->passes = passes;
         stats->kernel_ms = ms;
         for (int c = 0; c < 4; ++c) {
-            stats->closest_work[c] = (int64_t)(hw[c] + hw[8 + c] + hw[16 + c]); stats->any_work[c] = (int64_t)(hw[4 + c] + hw[12 + c] + hw[20 + c]);
+            // (the path kernel counts box tests and triangle records only; its slots 2, 3 hold the RT_PATH_DIAG diagnostics)
+            stats->closest_work[c] = (int64_t)(hw[c] + hw[8 + c] + (c < 2 ? hw[16 + c] : 0)); stats->any_work[c] = (int64_t)(hw[4 + c] + hw[12 + c] + (c < 2 ? hw[20 + c] : 0));
             stats->lane_closest_work[c] = (int64_t)hw[8 + c]; stats->lane_any_work[c] = (int64_t)hw[12 + c];
         }
+        if (d_work && getenv("RT_PATH_DIAG"))
+            fprintf(stderr, "path kernel: %llu wave steps, %.1f lanes stepping per step; %llu events, %.1f lanes waiting per event\n", hw[18],
+                    hw[18] ? (double)hw[19] / (double)hw[18] : 0.0, hw[22], hw[22] ? (double)hw[23] / (double)hw[22] : 0.0);
         stats->path_work[0] = (int64_t)hw[16]; stats->path_work[1] = (int64_t)hw[17]; stats->path_work[2] = (int64_t)hw[20]; stats->path_work[3] = (int64_t)hw[21];
         stats->path_roots = path_roots; stats->path_closest_rays = (int64_t)h[5]; stats->path_shadow_rays = (int64_t)h[6];
         for (size_t i = 0; i + 3 < kev.size(); i += 4) {

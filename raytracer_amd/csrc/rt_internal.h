@@ -272,7 +272,7 @@ size_t rtk_paths_stack_bytes(int64_t n, int depth0, int max_depth);
 hipError_t rtk_paths(const DevSceneView& sc, const rt_ray* rays, const int32_t* pix, const float* w, const float* nr,
                      const uint32_t* code, int64_t n, int depth0, int max_depth, float eps_f, float ambient, const float eye[3],
                      float start_nr, uint64_t seed, float light_radius, float glossy, float* contrib, void* stack,
-                     unsigned long long* counters, unsigned long long* work, hipStream_t st);
+                     unsigned long long* counters, unsigned long long* work, hipStream_t st, const int32_t* order = nullptr);
 
 // kernels_shade.hip
 hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,

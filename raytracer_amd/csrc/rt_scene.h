@@ -28,7 +28,7 @@ struct rt_scene {
     int knn_fast = 1;                 // radiance estimate: 1 = wave-shared kernel (default), 0 = strict list replay
     int fused_primary = 1;            // rt_render with primary_only: one kernel for the whole frame (RT_OPT_FUSED_PRIMARY)
     int lane_depth = 2;               // rt_render: passes of this depth and deeper trace per lane (RT_OPT_LANE_DEPTH)
-    int path_depth = 2;               // rt_render: rays of this depth and deeper are traced as whole subtrees of the recursion by ONE
+    int path_depth = 3;               // rt_render: rays of this depth and deeper are traced as whole subtrees of the recursion by ONE
                                       // persistent kernel (kernels_paths.hip, RT_OPT_PATH_DEPTH); a value above max_depth: never
     int ray_sort = 0;                 // rt_render: per-lane passes hand rays to lanes in (cell, octant, Morton) order (RT_OPT_RAY_SORT;
                                       // measured slower on BASELINE configuration 3, DESIGN 4.1c, so off by default)

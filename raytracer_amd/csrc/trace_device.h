@@ -871,6 +871,9 @@ __device__ __forceinline__ void bvh_lane_step(const DevSceneView& sc, BvhLaneWal
     float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
     if (k_node || k_tri || k_accgo) { q0 = reinterpret_cast<const float4*>(p)[0]; q1 = reinterpret_cast<const float4*>(p)[1]; }   // (a lane without a fetch asks the texture path for nothing)
     if (k_tri) q2 = reinterpret_cast<const float4*>(p)[2];
+#ifdef RT_EXP_EXTRA_LOAD
+    if (k_node) { const float4 qx = reinterpret_cast<const float4*>(p)[1]; asm volatile("" :: "v"(qx.x), "v"(qx.y), "v"(qx.z), "v"(qx.w)); }
+#endif
     const Rayf& r = wk.r;
     if (k_node) {                                                           // bvh_lane_next_leaf_c32_lim, one trip
         const BvhConsts& b = wk.bc;
@@ -944,6 +947,46 @@ __device__ __forceinline__ void bvh_lane_step(const DevSceneView& sc, BvhLaneWal
             }
         }
     }
+}
+
+// A wave's pool of claimed rays [next, end) for the refilling per-lane kernels: ONE atomic per chunk, not per refill -- a
+// device-scope atomic on a word that thousands of waves share is the slowest thing such a kernel does (measured: with one
+// atomic per refill of 8 lanes the single-step kernels lost 20 % to it).  The launch's rays are eight contiguous ranges
+// with a counter each (sc.ray_counter); a wave starts in the range of its workgroup's XCD label and moves on when its
+// own is used up, so the rays one L2 serves at a time come from one part of the queue.  Chunks shrink as a range runs out
+// (guided: about half a fair share of what was left at the wave's last claim, between 16 and sc.lane_chunk), so no wave
+// sits on a long private queue while the others are done.  All members are wave-uniform.
+struct RayPool { int64_t next, end, left_seen; int cur, spent; };
+__device__ __forceinline__ void ray_pool_init(RayPool& p, int64_t n) {
+    p.next = p.end = 0; p.left_seen = n >> 3; p.cur = (int)(blockIdx.x & 7u); p.spent = 0;
+}
+// makes the pool non-empty; false: every ray of the launch has been claimed
+__device__ __forceinline__ bool ray_pool_fill(const DevSceneView& sc, RayPool& p, int64_t n, int lane) {
+    while (p.next >= p.end) {
+        if (p.spent >= 8) return false;
+        const int64_t lo = (n * p.cur) >> 3, hi = (n * (p.cur + 1)) >> 3;
+        const int64_t share = (int64_t)(gridDim.x >> 2 ? gridDim.x >> 2 : 1);       // 1/8 of the waves start in a range: half a fair share each
+        int64_t want = p.left_seen / share;
+        want = want < 16 ? 16 : (want > sc.lane_chunk ? sc.lane_chunk : want);
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(sc.ray_counter + p.cur, (unsigned long long)want);
+        base = __shfl(base, 0, 64);
+        if ((int64_t)base >= hi - lo) { p.cur = (p.cur + 1) & 7; ++p.spent; p.left_seen = n >> 3; }
+        else {
+            p.next = lo + (int64_t)base;
+            p.end = p.next + want < hi ? p.next + want : hi;
+            p.left_seen = hi - p.end;
+        }
+    }
+    return true;
+}
+// the lanes of `need` take the pool's next rays in lane order; returns this lane's ray or -1 (not asking, or the pool ran out)
+__device__ __forceinline__ int64_t ray_pool_take(RayPool& p, unsigned long long need, int lane) {
+    const int64_t claim = p.next + __builtin_popcountll(need & ((1ull << lane) - 1ull));
+    const bool mine = ((need >> lane) & 1ull) != 0ull && claim < p.end;
+    const int64_t took = p.next + __builtin_popcountll(need);
+    p.next = took < p.end ? took : p.end;
+    return mine ? claim : (int64_t)-1;
 }
 
 // primitives outside every tree, in index order (the whole scene for final.cpp)
