@@ -167,6 +167,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     const bool check_layouts = getenv("RT_CHECK_LAYOUTS") && atoi(getenv("RT_CHECK_LAYOUTS")) != 0;
     const bool host_layouts = getenv("RT_HOST_LAYOUTS") && atoi(getenv("RT_HOST_LAYOUTS")) != 0;
     flat.host_layouts = host_layouts || check_layouts;
+    flat.device = dev;
     const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tb0 = now();

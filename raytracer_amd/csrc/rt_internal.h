@@ -203,6 +203,7 @@ struct HostFlatScene {
                                                // host_layouts is set (the device derives them: kernels_build.hip)
     std::vector<int32_t> kd_roots;             // first node of every object's tree in nodes[7]
     bool host_layouts = false;
+    int device = -1;                           // the scene's device (for the device half of the build: kernels_kdbuild.hip); -1: host only
     rt_uvec<DevLeafTri> leaf_tris;
     rt_uvec<DevLeafGroup> leaf_groups;
     rt_uvec<int32_t> rank_prim;                // the triangle (scene prim) of the leaf record with visit rank r
@@ -222,6 +223,10 @@ struct HostFlatScene {
     int64_t ntri = 0, nsphere = 0;
 };
 
+// kernels_kdbuild.hip: KDNode::BuildKD on the device, one tree; the result breadth-first
+struct RtKdBfsNode { float center[3], extend[3]; int32_t axis, cnt, child, leaf_off; };   // child: left child's index (right follows), -1 = a leaf
+int rtk_kd_build_device(int device, const rt_prim* prims, int32_t id0, int64_t nprims, const int32_t* ids, int64_t nt, float model_scale,
+                        std::vector<RtKdBfsNode>* nodes, std::vector<int32_t>* leaf_ids, int32_t* max_depth, std::string* err);
 // scene_build.cpp
 int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string* err);
 int rt_build_bvh(const rt_scene_desc* d, HostFlatScene* flat, std::string* err);      // bvh_build.cpp

@@ -180,6 +180,45 @@ struct Builder {
     }
 };
 
+// the device build's breadth-first nodes (kernels_kdbuild.hip) as the tree the flattener reads
+void from_bfs(BuildNode& n, const std::vector<RtKdBfsNode>& v, int32_t i, const std::vector<int32_t>& leaf_ids) {
+    const RtKdBfsNode& s = v[(size_t)i];
+    for (int k = 0; k < 3; ++k) { n.center[k] = s.center[k]; n.extend[k] = s.extend[k]; }
+    n.axis = s.axis;
+    if (s.child < 0) {
+        n.leaf = true;
+        n.prims.assign(leaf_ids.begin() + s.leaf_off, leaf_ids.begin() + s.leaf_off + s.cnt);
+        return;
+    }
+    n.left.reset(new BuildNode()); n.right.reset(new BuildNode());
+    from_bfs(*n.left, v, s.child, leaf_ids);
+    from_bfs(*n.right, v, s.child + 1, leaf_ids);
+}
+// ... with the subtrees below the first levels made by all threads
+void from_bfs_parallel(BuildNode& root, const std::vector<RtKdBfsNode>& v, const std::vector<int32_t>& leaf_ids, int nt) {
+    struct Job { BuildNode* n; int32_t i; };
+    std::vector<Job> level{{&root, 0}}, jobs;
+    for (int depth = 0; depth < 8 && !level.empty(); ++depth) {
+        std::vector<Job> next;
+        for (const Job& j : level) {
+            const RtKdBfsNode& s = v[(size_t)j.i];
+            if (s.child < 0) { jobs.push_back(j); continue; }
+            for (int k = 0; k < 3; ++k) { j.n->center[k] = s.center[k]; j.n->extend[k] = s.extend[k]; }
+            j.n->axis = s.axis;
+            j.n->left.reset(new BuildNode()); j.n->right.reset(new BuildNode());
+            next.push_back(Job{j.n->left.get(), s.child}); next.push_back(Job{j.n->right.get(), s.child + 1});
+        }
+        level.swap(next);
+    }
+    jobs.insert(jobs.end(), level.begin(), level.end());
+    rt_parallel_tasks((int64_t)jobs.size(), nt, [&](int64_t k) { from_bfs(*jobs[(size_t)k].n, v, jobs[(size_t)k].i, leaf_ids); });
+}
+bool same_tree(const BuildNode& a, const BuildNode& b) {
+    if (a.leaf != b.leaf || memcmp(a.center, b.center, 12) != 0 || memcmp(a.extend, b.extend, 12) != 0 || a.axis != b.axis) return false;
+    if (a.leaf) return a.prims == b.prims;
+    return same_tree(*a.left, *b.left) && same_tree(*a.right, *b.right);
+}
+
 void fill_tri(float* a, const float* f) {
     for (int k = 0; k < 3; ++k) {
         a[k] = f[k];
@@ -387,18 +426,53 @@ int rt_build_flat_scene(const rt_scene_desc* d, HostFlatScene* out, std::string*
         root.model_scale = tempF < 1.5f ? 1.5f : tempF;
         const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         const int nt = rt_host_threads();
-        Builder b;
-        b.prims = d->prims; b.nt = nt;
-        b.par_step = nt > 1 ? std::max<size_t>((size_t)1 << 16, root.prims.size() / (size_t)(4 * nt)) : SIZE_MAX;
-        b.run(root);
-        out->kd_nodes_built += b.built.load();
-        out->kd_max_depth = std::max(out->kd_max_depth, b.max_depth.load());
-        if (b.max_depth.load() + 1 > 250) { *err = "KD-tree deeper than 250 levels"; return RT_E_LIMIT; }
+        // Where: on the device (kernels_kdbuild.hip: every node of a level at once) from RT_KD_DEVICE_MIN triangles up, on
+        // the host's threads below that and whenever the device build declines (no device, workspace exceeded).
+        // RT_KD_BUILD=host|device forces either; RT_CHECK_KD=1 builds both and fails unless the trees are the same.
+        const int kd_mode = [] { const char* e = getenv("RT_KD_BUILD"); return !e ? 0 : (strcmp(e, "host") == 0 ? 1 : (strcmp(e, "device") == 0 ? 2 : 0)); }();
+        const int64_t kd_device_min = [] { const char* e = getenv("RT_KD_DEVICE_MIN"); return e && atoll(e) > 0 ? atoll(e) : (int64_t)500000; }();
+        const bool kd_check = [] { const char* e = getenv("RT_CHECK_KD"); return e && atoi(e) != 0; }();
+        int64_t built_nodes = 0; int32_t tree_depth = 0;
+        bool on_device = false;
+        if (out->device >= 0 && kd_mode != 1 && (kd_mode == 2 || kd_check || (int64_t)root.prims.size() >= kd_device_min)) {
+            std::vector<RtKdBfsNode> bfs; std::vector<int32_t> leaf_ids;
+            const int rcd = rtk_kd_build_device(out->device, d->prims + first, (int32_t)first, cnt, root.prims.data(), (int64_t)root.prims.size(), root.model_scale,
+                                                &bfs, &leaf_ids, &tree_depth, err);
+            if (rcd < 0) return rcd;
+            if (rcd == 0) {
+                on_device = true;
+                built_nodes = (int64_t)bfs.size();
+                std::vector<int32_t> all; all.swap(root.prims);
+                const double tt = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                from_bfs_parallel(root, bfs, leaf_ids, nt);
+                if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "KD build: tree from the device's nodes %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tt);
+                if (kd_check) {
+                    BuildNode ref; ref.prims.swap(all); ref.model_scale = root.model_scale;
+                    Builder bh;
+                    bh.prims = d->prims; bh.nt = nt;
+                    bh.par_step = nt > 1 ? std::max<size_t>((size_t)1 << 16, ref.prims.size() / (size_t)(4 * nt)) : SIZE_MAX;
+                    bh.run(ref);
+                    if (bh.built.load() != built_nodes || bh.max_depth.load() != tree_depth || !same_tree(root, ref)) {
+                        *err = "RT_CHECK_KD: the device-built KD-tree differs from the host-built one"; return RT_E_INVALID;
+                    }
+                }
+            } else if (kd_mode == 2 && getenv("RT_BUILD_TIMING")) fprintf(stderr, "KD build: the device build declined, building on the host\n");
+        }
+        if (!on_device) {
+            Builder b;
+            b.prims = d->prims; b.nt = nt;
+            b.par_step = nt > 1 ? std::max<size_t>((size_t)1 << 16, root.prims.size() / (size_t)(4 * nt)) : SIZE_MAX;
+            b.run(root);
+            built_nodes = b.built.load(); tree_depth = b.max_depth.load();
+        }
+        out->kd_nodes_built += built_nodes;
+        out->kd_max_depth = std::max(out->kd_max_depth, tree_depth);
+        if (tree_depth + 1 > 250) { *err = "KD-tree deeper than 250 levels"; return RT_E_LIMIT; }
         const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t1 = now();
         Flattener f{d, out, dbg_slack_scale()};
-        for (int o = out->host_layouts ? 0 : 7; o < 8; ++o) out->nodes[o].reserve(out->nodes[o].size() + (size_t)b.built.load());
+        for (int o = out->host_layouts ? 0 : 7; o < 8; ++o) out->nodes[o].reserve(out->nodes[o].size() + (size_t)built_nodes);
         f.make_leaves(root);
         const double t2 = now();
         out->kd_roots.push_back((int32_t)out->nodes[7].size());

@@ -67,3 +67,65 @@ def test_device_layouts_equal_the_hosts(check_layouts, name):
         assert (out["strict"] >= 0).sum() > 100
     finally:
         g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# KDNode::BuildKD on the device (kernels_kdbuild.hip; hw4.cpp:330-490): RT_CHECK_KD=1 makes rt_scene_create build every
+# object's tree on the device AND on the host and fails the call unless node count, depth, every node's centre / extent /
+# axis and every leaf's list (order included) are the same; the arrays the kernels read are made from that tree by the
+# same host code either way.  The default takes the device from RT_KD_DEVICE_MIN triangles up.
+
+@pytest.fixture()
+def check_kd():
+    os.environ["RT_CHECK_KD"] = "1"
+    yield
+    os.environ.pop("RT_CHECK_KD", None)
+
+
+def _duplicates_and_ties():
+    """a mesh with every triangle twice, a block of identical triangles and coordinates that tie on the split planes"""
+    a = synth.mesh_scene(40, 30, seed=5)
+    p = np.asarray(a.prims).reshape(-1, 12)
+    q = np.round(p[2:] * 8) / 8                                      # vertices on a coarse lattice: many equal coordinates
+    prims = np.concatenate([p[:2], p[2:], p[2:], q, np.repeat(p[5:6], 300, axis=0)]).astype(np.float32)
+    import dataclasses
+    return dataclasses.replace(a, prims=prims, prim_type=np.full(len(prims), a.prim_type[0], a.prim_type.dtype),
+                               prim_material=np.zeros(len(prims), np.int32), obj_first=np.array([0, 2], np.int64),
+                               obj_count=np.array([2, len(prims) - 2], np.int64))
+
+
+@pytest.mark.parametrize("name", ["monkey", "objects", "ties", "mesh_300k"])
+def test_device_kd_build_equals_the_host_build(check_kd, name):
+    if name == "monkey":
+        sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "monkey.txt"))
+    elif name == "objects":
+        sd = _several_objects()
+    elif name == "ties":
+        sd = _duplicates_and_ties()
+    else:
+        sd = synth.mesh_scene(500, 300)
+    g = host.Scene(sd)                 # raises RtError("RT_CHECK_KD: ...") on any difference
+    try:
+        inf = g.info()
+        if name == "monkey":           # the reference's own log: 138 nodes, depth 9 (HW4/hw4/executionTime_monkey.txt:4-5)
+            assert inf.kd_nodes_built == 138 and inf.kd_max_depth == 9
+        assert inf.flat_nodes >= 1
+    finally:
+        g.close()
+
+
+def test_device_built_tree_gives_the_reference_hits():
+    """the monkey's tree built on the device alone (RT_KD_BUILD=device): the reference's 65 536 primary rays find the reference's triangles"""
+    os.environ["RT_KD_BUILD"] = "device"
+    try:
+        sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "monkey.txt"))
+        g = host.Scene(sd)
+    finally:
+        os.environ.pop("RT_KD_BUILD", None)
+    try:
+        gold = np.load(os.path.join(ol.GOLDEN, "monkey256_hits.npz"))
+        for mode in ("strict", "fast", "bvh"):          # the reference's own primary rays and the triangles it found for them
+            g.set_traversal(mode)
+            assert np.array_equal(g.trace_closest(np.ascontiguousarray(gold["rays"]))["prim"], gold["prim"]), mode
+    finally:
+        g.close()
