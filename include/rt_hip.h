@@ -299,7 +299,7 @@ int rt_scene_info_get(const rt_scene* s, rt_scene_info* info);
  * 0 = every kernel on the caller's stream (also what rt_stats' per-kernel times should be read from: kernels that share
  * the chip time each other).  RT_RENDER_OVERLAP=0|1.                                                                     */
 #define RT_OPT_RENDER_OVERLAP 7
-/* RT_OPT_PATH_DEPTH (default 2; no counterpart: the reference recurses): with RT_TRAVERSAL_FAST or _BVH, rt_render hands the
+/* RT_OPT_PATH_DEPTH (default 3; no counterpart: the reference recurses): with RT_TRAVERSAL_FAST or _BVH, rt_render hands the
  * rays of recursion depth >= value to ONE persistent kernel in which a lane follows a ray's whole subtree of the
  * recursion -- closest hit, shadow rays, shading, reflected and refracted children, depth first -- instead of one
  * pass of kernels per depth with a host round trip between them.  Same hits, same shadow bits, same
