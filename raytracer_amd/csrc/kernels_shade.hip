@@ -215,7 +215,7 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         const int32_t* __restrict__ pix, const float* __restrict__ weight, const float* __restrict__ nr_in,
         const uint8_t* __restrict__ flags, int64_t nflags, const uint32_t* __restrict__ block_offsets,
         rt_ray* __restrict__ orays, int32_t* __restrict__ opix, float* __restrict__ oweight, float* __restrict__ onr,
-        unsigned long long* __restrict__ counters, const uint32_t* __restrict__ code, uint32_t* __restrict__ ocode,
+        unsigned int* __restrict__ kind_pairs, const uint32_t* __restrict__ code, uint32_t* __restrict__ ocode,
         uint64_t seed, float glossy, uint8_t* __restrict__ ooct) {
     __shared__ uint32_t wsum[SCAN_BLOCK / 64];
     __shared__ unsigned int kinds[2];
@@ -262,7 +262,9 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
     if (nrefl) atomicAdd(&kinds[0], (unsigned)nrefl);
     if (nrefr) atomicAdd(&kinds[1], (unsigned)nrefr);
     __syncthreads();
-    if (threadIdx.x < 2 && kinds[threadIdx.x]) atomicAdd(counters + 3 + threadIdx.x, (unsigned long long)kinds[threadIdx.x]);
+    // the block's two counts go to its own pair; k_reduce_pairs adds them up (one global atomic per block on one word --
+    // 130 000 of them for the 132.7 M rays of config 3's first pass -- cost more than the compaction itself)
+    if (threadIdx.x < 2) kind_pairs[2 * blockIdx.x + threadIdx.x] = kinds[threadIdx.x];
 }
 
 // ---- stable partition of a queue by direction octant (the order in which a wave-synchronous pass takes its rays) -------
@@ -423,8 +425,11 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
     const int64_t nb = rtk_scan_blocks_needed(nflags);
     hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, nflags, block_sums);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, nb, d_total);
+    // block_sums: [nb] offsets, then (256-byte aligned) [nb][2] per-block child counts by kind
+    unsigned int* kind_pairs = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(block_sums) + (((size_t)nb * 4 + 16 + 255) & ~(size_t)255));
     hipLaunchKernelGGL(k_spawn, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, sc, rays, hits, pix, weight, nr_in, flags,
-                       nflags, block_sums, orays, opix, oweight, onr, counters, code, ocode, seed, glossy, ooct);
+                       nflags, block_sums, orays, opix, oweight, onr, kind_pairs, code, ocode, seed, glossy, ooct);
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, kind_pairs, nb, counters + 3);      // [3] reflect, [4] refract children
     return hipGetLastError();
 }
 

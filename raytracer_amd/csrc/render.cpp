@@ -255,7 +255,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
         RTCHK(s->scratch(S_CONTRIB, (size_t)n * 12, &contrib));
         if (spawn) {
             RTCHK(s->scratch(S_FLAGS, (size_t)n * 2, &flags));
-            RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 4 + 16, &bsums));
+            RTCHK(s->scratch(S_BSUMS, (size_t)rtk_scan_blocks_needed(2 * n) * 12 + 1024, &bsums));     // offsets + per-block child counts (rtk_compact_children)
         }
         // per-lane passes: rays go to lanes in spatial / octant order (RT_OPT_RAY_SORT); the sort is timed with the pass
         const bool sorted = pass_mode == 2 && s->ray_sort && s->view.nbvh > 0 && (s->fast == 1 || s->fast == 3);
