@@ -466,11 +466,33 @@ __device__ __forceinline__ void consider_uniform(float (&hd)[REDO_S], int (&hi)[
 }
 }  // namespace
 
+// WALK 1 (default): LocatePhoton's recursion on an explicit stack, and whole six-level windows of the heap skipped at once.
+// The reference visits: the near child's subtree, the far child's if dist1^2 < np.dist2[0] AT THAT TIME, then the node
+// itself (photon.cpp:53-131).  Two facts make the walk cheap without changing what it accepts or in which order:
+//  (1) a photon below a far step with dist1^2 = m has dist2 >= m (the heap's median split; float subtraction, product and
+//      sum are monotone), and np.dist2[0] only shrinks -- so a subtree whose path from the root holds a far step with
+//      m >= np.dist2[0] NOW cannot contain a photon that will ever be accepted: it is skipped, whether or not the reference
+//      would still be inside it; visiting a subtree the reference prunes is harmless for the same reason;
+//  (2) a node whose dist2 is not below np.dist2[0] now never will be.
+// So when the 63 nodes of the window below a node (one fetch by 63 lanes) hold no candidate, the walk does not step
+// through them: every lane derives for its node, level by level, whether the walk reaches it and the largest m on its
+// path, the 64 subtrees below the window are put on the stack in the reference's visiting order (near before far at every
+// level) with their m, and the window's own nodes are dropped.  Where the caustic map's heap has no spatial order --
+// coplanar photons: every third level splits on the axis all photons share, dist1 = 0, both sides always visited -- the
+// reference's walk is hundreds of thousands of nodes long (200 ms for ONE query, the whole of config 4's strict-redo cost);
+// it becomes a few thousand windows.  A window with a candidate is walked node by node from the stack.
+// WALK 0: the stackless walk of rounds 1-2 (RT_KNN_REDO_WALK=0).
+template <int WALK>
 __global__ void __launch_bounds__(64)
 k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
                   const float* __restrict__ nrm3, int k, float maxDist, float* __restrict__ out_rgb,
                   const float* __restrict__ tables, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist) {
     __shared__ float4 win[64];
+    __shared__ unsigned stk_i[WALK ? 512 : 1];                      // WALK 1: pending items: node | kind << 30 (0 subtree, 2 the node itself)
+    __shared__ float stk_m[WALK ? 512 : 1];                         // ... and the largest far-step dist1^2 on the way to it (-1: none)
+    __shared__ unsigned ord_i[WALK ? 64 : 1];                       // a window's exits by visiting order
+    __shared__ float ord_m[WALK ? 64 : 1];
+    __shared__ int ord_v[WALK ? 64 : 1];
     const int lane = threadIdx.x;
     const int wd = 31 - __builtin_clz((unsigned)lane + 1u);        // this lane's node of a window: level wd, position wj
     const unsigned wj = (unsigned)lane + 1u - (1u << wd);
@@ -480,9 +502,116 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
         const int64_t i = list[jq];
         const float qx = pos3[3 * i], qy = pos3[3 * i + 1], qz = pos3[3 * i + 2];
         float hd[REDO_S] = {0.f, 0.f}; int hi[REDO_S] = {0, 0};
-        float st1 = 0.f, st2 = 0.f;                                 // LocatePhoton's dist1 / this node's dist2 per level, level l in lane l
         float r2 = maxDist * maxDist;                               // np.dist2[0], photon.cpp:405
         int found = 0, got_heap = 0;
+        if (WALK == 1) {
+            int sp = 0;
+            if (n >= 1) { if (lane == 0) { stk_i[0] = 1u; stk_m[0] = -1.0f; } sp = 1; }
+            __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+            while (sp > 0) {
+                --sp;
+                const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)stk_i[sp]);
+                const float m0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(stk_m[sp])));
+                const unsigned idx = item & 0x3fffffffu;
+                if ((item >> 30) == 2u) {                           // the node itself, after both subtrees
+                    const float4 rec = *reinterpret_cast<const float4*>(ph + idx);
+                    float d1 = rec.x - qx; float dist2 = d1 * d1;
+                    d1 = rec.y - qy; dist2 += d1 * d1;
+                    d1 = rec.z - qz; dist2 += d1 * d1;
+                    consider_uniform(hd, hi, lane, k, found, got_heap, r2, (int)idx, rl_f(dist2, 0));
+                    continue;
+                }
+                if (!(m0 < r2)) continue;                           // (1): nothing below can be accepted any more
+                if (idx >= uhalf) {                                 // no recursion below this index (photon.cpp:58): the node alone
+                    const float4 rec = *reinterpret_cast<const float4*>(ph + idx);
+                    float d1 = rec.x - qx; float dist2 = d1 * d1;
+                    d1 = rec.y - qy; dist2 += d1 * d1;
+                    d1 = rec.z - qz; dist2 += d1 * d1;
+                    consider_uniform(hd, hi, lane, k, found, got_heap, r2, (int)idx, rl_f(dist2, 0));
+                    continue;
+                }
+                // the window below idx: six levels, or what the heap still has (a node from `uhalf` on does not recurse, one beyond
+                // n does not exist); the stack must hold its 64 exits
+                const bool fits = idx < (1u << 23) && sp + 64 + 100 <= 512;
+                bool expanded = false;
+                if (fits) {
+                    const unsigned node = (idx << wd) + wj;
+                    const bool exists = lane < 63 && (unsigned long long)node <= (unsigned long long)n;
+                    const int recurses = (exists && node < uhalf) ? 1 : 0;
+                    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (exists) rec = *reinterpret_cast<const float4*>(ph + node);
+                    float d1 = rec.x - qx; float dist2 = d1 * d1;
+                    d1 = rec.y - qy; dist2 += d1 * d1;
+                    d1 = rec.z - qz; dist2 += d1 * d1;
+                    if (__ballot(exists && dist2 < r2) == 0ull) {
+                        const int plane = __float_as_int(rec.w) & 3;
+                        const float pp = plane == 0 ? rec.x : (plane == 1 ? rec.y : rec.z);
+                        const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
+                        const float dist1 = qp - pp;                // photon.cpp:61
+                        const float d1sq = dist1 * dist1;
+                        const int near_right = dist1 > 0.0f ? 1 : 0;
+                        // reached? and the largest far-step dist1^2 on the path, root of the window first
+                        int vis = lane == 0 ? 1 : 0;
+                        float req = m0;
+                        unsigned key = 0u;
+                        const int plane_of_parent = (lane + 1) / 2 - 1;      // the parent's lane (window node w = lane + 1, parent w / 2)
+                        const int is_right = (lane + 1) & 1;
+#pragma unroll
+                        for (int lv = 1; lv <= 5; ++lv) {
+                            const int pv = __shfl(vis, plane_of_parent, 64) & __shfl(recurses, plane_of_parent, 64), pn = __shfl(near_right, plane_of_parent, 64);
+                            const float pr = __shfl(req, plane_of_parent, 64), pd = __shfl(d1sq, plane_of_parent, 64);
+                            const unsigned pk = (unsigned)__shfl((int)key, plane_of_parent, 64);
+                            if (wd == lv && lane < 63) {
+                                const bool near = is_right == pn;
+                                req = near ? pr : __builtin_fmaxf(pr, pd);
+                                vis = (pv && exists && req < r2) ? 1 : 0;
+                                key = (pk << 1) | (near ? 0u : 1u);
+                            }
+                        }
+                        // the 64 subtrees below the window: exit e = child (e & 1) of the level-5 node e >> 1 (lane 31 + (e >> 1))
+                        {
+                            const int pl = 31 + (lane >> 1);
+                            const int pv = __shfl(vis, pl, 64) & __shfl(recurses, pl, 64), pn = __shfl(near_right, pl, 64);
+                            const float pr = __shfl(req, pl, 64), pd = __shfl(d1sq, pl, 64);
+                            const unsigned pk = (unsigned)__shfl((int)key, pl, 64);
+                            const bool near = (lane & 1) == pn;
+                            const float ereq = near ? pr : __builtin_fmaxf(pr, pd);
+                            const int evis = (pv && ereq < r2) ? 1 : 0;
+                            const unsigned ekey = (pk << 1) | (near ? 0u : 1u);          // 6 bits: the visiting order
+                            ord_i[ekey] = (idx << 6) + (unsigned)lane; ord_m[ekey] = ereq; ord_v[ekey] = evis;
+                        }
+                        __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                        const int v = ord_v[lane];
+                        const unsigned long long mask = __ballot(v != 0);
+                        if (v) {                                     // the first to be visited on top
+                            const int above = lane == 63 ? 0 : __builtin_popcountll(mask >> (lane + 1));
+                            stk_i[sp + above] = ord_i[lane]; stk_m[sp + above] = ord_m[lane];
+                        }
+                        sp += __builtin_popcountll(mask);
+                        __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                        expanded = true;
+                    }
+                }
+                if (expanded) continue;
+                // one node: its own turn after both subtrees, the far subtree after the near one
+                {
+                    const float4 rec = *reinterpret_cast<const float4*>(ph + idx);
+                    const int plane = __builtin_amdgcn_readfirstlane(__float_as_int(rec.w)) & 3;
+                    const float pp = rl_f(plane == 0 ? rec.x : (plane == 1 ? rec.y : rec.z), 0);
+                    const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
+                    const float dist1 = qp - pp;
+                    const unsigned near = (dist1 > 0.0f) ? 2u * idx + 1u : 2u * idx;
+                    if (lane == 0) {
+                        stk_i[sp] = idx | (2u << 30); stk_m[sp] = -1.0f;
+                        stk_i[sp + 1] = near ^ 1u; stk_m[sp + 1] = __builtin_fmaxf(m0, dist1 * dist1);
+                        stk_i[sp + 2] = near; stk_m[sp + 2] = m0;
+                    }
+                    sp += 3;
+                    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                }
+            }
+        } else {
+        float st1 = 0.f, st2 = 0.f;                                 // LocatePhoton's dist1 / this node's dist2 per level, level l in lane l
         bool done = n < 1;
         unsigned idx = 1, wroot = 0;
         while (!done) {
@@ -530,6 +659,7 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
                 cidx = (int)idx; cd2 = rl_f(st2, lvl);
             }
         }
+        }
         // CalcIrradiance, photon.cpp:405-441: the sum over np.index[1 .. found] in that order
         float r = 0.f, g = 0.f, b = 0.f;
         if (found >= 8) {                                           // literal 8, photon.cpp:411
@@ -572,7 +702,7 @@ size_t rtk_knn_fast_scratch_bytes(int64_t q) {
 hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, unsigned long long* d_stats,
                                const float* d_pos3, const float* d_nrm3,
                                int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
-                               float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st) {
+                               float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st, hipStream_t redo_st) {
     if (q <= 0) return hipSuccess;
     if (k > 112 || !d_flagged) return hipErrorInvalidValue;
     static const bool use_coop = getenv("RT_KNN_COOP") != nullptr;       // the 16-lane kernel for mode 1 too (experiments)
@@ -584,11 +714,40 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
         void* work = (void*)(list + (((size_t)q + 63) & ~(size_t)63));
         hipError_t e = hipMemsetAsync(nlist, 0, 4, st);
         if (e != hipSuccess) return e;
+        static const bool trace = getenv("RT_KNN_TRACE") != nullptr;      // per call: queries, flagged queries, ms of the main kernel and of the redo (synchronises)
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        if (trace) { for (auto& x : ev) (void)hipEventCreate(&x); (void)hipEventRecord(ev[0], st); }
         e = rtk_photon_irr_wave(ph, n, half, box6, d_pos3, d_nrm3, q, k, maxDist, d_rgb, d_tables, list, nlist, work, d_stats, st);
         if (e != hipSuccess) return e;
+        if (trace) (void)hipEventRecord(ev[1], st);
         if (k + 1 <= 64 * REDO_S - 1 && !getenv("RT_KNN_REDO_LDS")) {
-            hipLaunchKernelGGL(k_photon_knn_redo, dim3(2048), dim3(64), 0, st, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
-                               (const int32_t*)list, (const unsigned*)nlist);
+            // redo_st (mode 1 only): the strict redo of the few flagged queries runs on that stream, after the main kernel --
+            // a handful of waves whose walks can take 100 ms where the reference's heap has no spatial order (coplanar
+            // photons), beside whatever the caller queues on `st` next.  The caller joins redo_st before it reads d_rgb.
+            hipStream_t rs = st;
+            if (redo_st && redo_st != st && !trace) {
+                hipEvent_t done = nullptr;
+                if ((e = hipEventCreateWithFlags(&done, hipEventDisableTiming)) != hipSuccess) return e;
+                e = hipEventRecord(done, st);
+                if (e == hipSuccess) e = hipStreamWaitEvent(redo_st, done, 0);
+                (void)hipEventDestroy(done);                        // released once it has completed
+                if (e != hipSuccess) return e;
+                rs = redo_st;
+            }
+            static const bool old_walk = [] { const char* v = getenv("RT_KNN_REDO_WALK"); return v && atoi(v) == 0; }();
+            if (old_walk || n >= ((int64_t)1 << 30))
+                hipLaunchKernelGGL(k_photon_knn_redo<0>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
+                                   (const int32_t*)list, (const unsigned*)nlist);
+            else
+                hipLaunchKernelGGL(k_photon_knn_redo<1>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
+                                   (const int32_t*)list, (const unsigned*)nlist);
+            if (trace) {
+                (void)hipEventRecord(ev[2], st); (void)hipEventSynchronize(ev[2]);
+                unsigned nl = 0; (void)hipMemcpy(&nl, nlist, 4, hipMemcpyDeviceToHost);
+                float a = 0.f, b = 0.f; (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+                fprintf(stderr, "kNN call: %lld photons, %lld queries, r %.3g: main %.3f ms, %u flagged, redo %.3f ms\n", (long long)n, (long long)q, (double)maxDist, a, nl, b);
+                for (auto& x : ev) (void)hipEventDestroy(x);
+            }
             return hipGetLastError();
         }
         return launch_knn<4>(ph, n, half, d_pos3, d_nrm3, q, k, maxDist, 1, d_idx, d_d2, d_found, d_r2, d_rgb, d_tables, nullptr, st, list, nlist);

@@ -22,9 +22,10 @@ enum {
     P_QA_RAYS, P_QA_SID, P_QA_W, P_QA_CODE, P_QB_RAYS, P_QB_SID, P_QB_W, P_QB_CODE,
     P_HITS, P_FLAGS, P_NRM, P_NRML, P_QPOS, P_CAUSTIC, P_OCC, P_CONTRIB, P_BSUMS,
     P_G_SLOTS,  // the gather queues and their per-ray arrays, carved from one slot (Arena)
-    P_KNN_FLAG  // queries the fast kNN kernel hands to the strict one
+    P_KNN_FLAG,   // queries the fast kNN kernel hands to the strict one
+    P_KNN_FLAG_C  // ... of the caustic map's calls, whose strict redo may still run while the global map's calls use the other
 };
-static_assert(P_KNN_FLAG + 1 <= RT_NSCRATCH, "not enough scratch slots");
+static_assert(P_KNN_FLAG_C + 1 <= RT_NSCRATCH, "not enough scratch slots");
 
 struct Arena {   // bump allocator over one scratch slot
     char* base = nullptr; size_t cap = 0, off = 0;
@@ -36,25 +37,26 @@ struct Arena {   // bump allocator over one scratch slot
     }
 };
 
-int knn_launch(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st);
+int knn_launch(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st, hipStream_t redo_st);
 
 // the radiance estimate, bracketed by events when the caller wants rt_stats.knn_ms
+// redo_st: the strict redo of the flagged queries goes to that stream (the caller joins it before reading rgb), or NULL
 int knn(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st,
-        EventBag* bag, std::vector<hipEvent_t>* kev) {
+        EventBag* bag, std::vector<hipEvent_t>* kev, hipStream_t redo_st = nullptr) {
     hipError_t err;
     if (bag) { hipEvent_t e = bag->mark(st, &err); if (!e) return rt_hipfail(err, "event"); kev->push_back(e); }
-    RTCHK(knn_launch(s, which, pos, nrm, q, k, radius, rgb, st));
+    RTCHK(knn_launch(s, which, pos, nrm, q, k, radius, rgb, st, redo_st));
     if (bag) { hipEvent_t e = bag->mark(st, &err); if (!e) return rt_hipfail(err, "event"); kev->push_back(e); }
     return RT_OK;
 }
 
-int knn_launch(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st) {
+int knn_launch(rt_scene* s, int which, const float* pos, const float* nrm, int64_t q, int k, float radius, float* rgb, hipStream_t st, hipStream_t redo_st) {
     const PhotonMapDev& m = s->pmap[which];
     if (!m.d_photons || m.n < 1) { HIPCHK(hipMemsetAsync(rgb, 0, (size_t)q * 12, st), "memset irradiance"); return RT_OK; }
     if (s->knn_fast && k <= RT_KNN_FAST_KMAX) {
-        void* fl; RTCHK(s->scratch(P_KNN_FLAG, rtk_knn_fast_scratch_bytes(q), &fl));
+        void* fl; RTCHK(s->scratch(which == RT_PMAP_CAUSTIC ? P_KNN_FLAG_C : P_KNN_FLAG, rtk_knn_fast_scratch_bytes(q), &fl));
         HIPCHK(rtk_photon_knn_fast(m.d_photons, m.n, m.half, m.box, s->d_knn_stats, pos, nrm, q, k, radius, 1, nullptr, nullptr, nullptr, nullptr, rgb,
-                                   s->d_dir_tables, (uint8_t*)fl, st), "k_photon_knn_coop");
+                                   s->d_dir_tables, (uint8_t*)fl, st, redo_st), "k_photon_knn_coop");
         return RT_OK;
     }
     HIPCHK(rtk_photon_knn(m.d_photons, m.n, m.half, pos, nrm, q, k, radius, 1, nullptr, nullptr, nullptr, nullptr, rgb,
@@ -94,6 +96,10 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
     uint32_t* d_total = (uint32_t*)(d_ctr + 8);
     HIPCHK(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long) + 16, st), "memset counters");
 
+    // the caustic estimate's strict redo beside the gather rays (below): not while per-call times are asked for (rt_stats:
+    // knn_ms brackets a whole call on one stream), not with RT_RENDER_OVERLAP=0
+    const bool side_redo = s->overlap_shadow && !stats && s->knn_fast;
+    if (side_redo && !s->aux_stream) HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking), "hipStreamCreate");
     EventBag bag;                          // destroyed on every return path
     std::vector<hipEvent_t> knn_ev;        // begin / end of every radiance-estimate call
     EventBag* kb = stats ? &bag : nullptr;
@@ -141,10 +147,26 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
                                 depth == 0 ? d_hit_ids : nullptr, (const int32_t*)pixmap, d_ctr, st), "k_pm_shade");
             HIPCHK(rtk_pm_shadow(s->view, (const rt_hit*)hits, q_sid, (const float*)nrmL, n, S, s->eps_f, s->fast,
                                  (uint8_t*)occ, d_ctr, st), "k_pm_shadow");
-            RTCHK(knn(s, RT_PMAP_CAUSTIC, (const float*)qpos, (const float*)nrm, n, K, p->knn_radius_caustic, (float*)caustic, st, kb, &knn_ev));
+            // The caustic estimate's strict redo -- a handful of queries with an exact tie, whose replay of the reference's walk
+            // takes up to 200 ms where the caustic map's heap has no spatial order (coplanar photons on the floor; 1.6 of the
+            // 4.3 s of config 4's frame) -- runs on the scene's second stream, followed there by what needs its result (direct
+            // light + caustic, and their accumulation), while this stream goes on with the gather rays; the gather's first
+            // accumulation waits for it, so every sample's additions keep their order and the frame its bytes.
+            const bool side = side_redo && G > 0 && depth + 1 <= p->irradiance_max_depth;
+            hipStream_t sd = side ? s->aux_stream : st;
+            RTCHK(knn(s, RT_PMAP_CAUSTIC, (const float*)qpos, (const float*)nrm, n, K, p->knn_radius_caustic, (float*)caustic, st, kb, &knn_ev,
+                      side ? sd : nullptr));
+            hipEvent_t direct_done = nullptr;
+            if (side) {         // (if nothing was flagged the redo stream has not waited for st yet: make it)
+                hipError_t err; hipEvent_t e = bag.mark(st, &err);
+                if (!e) return rt_hipfail(err, "event");
+                HIPCHK(hipStreamWaitEvent(sd, e, 0), "hipStreamWaitEvent");
+            }
             HIPCHK(rtk_pm_direct(s->view, (const rt_hit*)hits, q_sid, q_w, (const float*)nrmL, n, S, (const uint8_t*)occ,
-                                 (const float*)caustic, cam->center, (float*)contrib, st), "k_pm_direct");
-            HIPCHK(rtk_accumulate(q_sid, (const float*)contrib, n, (float*)accum, st), "k_accumulate");
+                                 (const float*)caustic, cam->center, (float*)contrib, sd), "k_pm_direct");
+            // (with the redo on the side, this pass's direct + caustic term joins the samples AFTER its gather terms: the whole
+            // gather loop, not just its first level, runs beside the redo; a fixed order either way)
+            if (!side) HIPCHK(rtk_accumulate(q_sid, (const float*)contrib, n, (float*)accum, st), "k_accumulate");
 
             // ---- global illumination: gather rays through TraceIrradiance (depth+1 .. IRRADIANCE_MAX_DEPTH) ----
             if (G > 0 && depth + 1 <= p->irradiance_max_depth) {
@@ -184,6 +206,15 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
                                         p->start_nr, gr[cur ^ 1], gs[cur ^ 1], gw[cur ^ 1], st), "k_gi_spawn");
                     gn = (int64_t)total; cur ^= 1;
                 }
+            }
+            if (side) {
+                hipError_t err; hipEvent_t e = bag.mark(st, &err);          // the gather terms are in
+                if (!e) return rt_hipfail(err, "event");
+                HIPCHK(hipStreamWaitEvent(sd, e, 0), "hipStreamWaitEvent");
+                HIPCHK(rtk_accumulate(q_sid, (const float*)contrib, n, (float*)accum, sd), "k_accumulate");
+                direct_done = bag.mark(sd, &err);
+                if (!direct_done) return rt_hipfail(err, "event");
+                HIPCHK(hipStreamWaitEvent(st, direct_done, 0), "hipStreamWaitEvent");
             }
             if (!spawn) break;
             // ---- children of the eye path -> the other queue ----

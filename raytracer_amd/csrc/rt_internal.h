@@ -363,7 +363,7 @@ hipError_t rtk_photon_knn(const DevPhoton* ph, int64_t n, int64_t half, const fl
 // cooperative kernel (mode 1 irradiance / mode 2 candidate set) + strict redo of the queries it flags; k <= 112
 hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, unsigned long long* d_stats, const float* d_pos3, const float* d_nrm3,
                                int64_t q, int k, float maxDist, int mode, int32_t* d_idx, float* d_d2, int32_t* d_found,
-                               float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st);
+                               float* d_r2, float* d_rgb, const float* d_tables, uint8_t* d_flagged, hipStream_t st, hipStream_t redo_st = nullptr);
 hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, const float* box6, const float* d_pos3, const float* d_nrm3,
                                int64_t q, int k, float maxDist, float* d_rgb, const float* d_tables, int32_t* d_redo_list,
                                unsigned* d_redo_count, void* d_work, unsigned long long* d_stats, hipStream_t st);
