@@ -150,13 +150,13 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
             // The caustic estimate's strict redo -- a handful of queries with an exact tie, whose replay of the reference's walk
             // takes up to 200 ms where the caustic map's heap has no spatial order (coplanar photons on the floor; 1.6 of the
             // 4.3 s of config 4's frame) -- runs on the scene's second stream, followed there by what needs its result (direct
-            // light + caustic, and their accumulation), while this stream goes on with the gather rays; the gather's first
-            // accumulation waits for it, so every sample's additions keep their order and the frame its bytes.
+            // light + caustic), while this stream goes on with the gather rays.  That term is accumulated on the second stream
+            // after the pass's gather terms (below), and the pass joins before its children are spawned: one fixed order of
+            // additions per sample, whatever the tiling.
             const bool side = side_redo && G > 0 && depth + 1 <= p->irradiance_max_depth;
             hipStream_t sd = side ? s->aux_stream : st;
             RTCHK(knn(s, RT_PMAP_CAUSTIC, (const float*)qpos, (const float*)nrm, n, K, p->knn_radius_caustic, (float*)caustic, st, kb, &knn_ev,
                       side ? sd : nullptr));
-            hipEvent_t direct_done = nullptr;
             if (side) {         // (if nothing was flagged the redo stream has not waited for st yet: make it)
                 hipError_t err; hipEvent_t e = bag.mark(st, &err);
                 if (!e) return rt_hipfail(err, "event");
@@ -212,7 +212,7 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
                 if (!e) return rt_hipfail(err, "event");
                 HIPCHK(hipStreamWaitEvent(sd, e, 0), "hipStreamWaitEvent");
                 HIPCHK(rtk_accumulate(q_sid, (const float*)contrib, n, (float*)accum, sd), "k_accumulate");
-                direct_done = bag.mark(sd, &err);
+                hipEvent_t direct_done = bag.mark(sd, &err);
                 if (!direct_done) return rt_hipfail(err, "event");
                 HIPCHK(hipStreamWaitEvent(st, direct_done, 0), "hipStreamWaitEvent");
             }

@@ -1,10 +1,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests/test_gpu_photon.py tests/test_gpu_photon_render.py tests/test_zz_no_alloc.py tests/test_gpu_config4_size.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/pm_tests.log 2>&1
-rc=$?; tail -n 6 gpurun_out/pm_tests.log; echo "pytest rc=$rc"
-if [ $rc -ne 0 ]; then exit $rc; fi
-for v in "RT_KNN_REDO_WALK=1" "RT_KNN_REDO_WALK=0"; do
-  echo "== $v"; env $v timeout -k 10 300 python -u tools/exp_pframe.py full 2>/dev/null | tail -n 1 | cut -c1-160 || exit $?
-  env $v timeout -k 10 300 python -u tools/exp_knn.py 2>/dev/null | tail -n 1 | cut -c1-100 || exit $?
+for v in "RT_BVH_LEAF=6" "RT_BVH_LEAF=3" "RT_BVH_LEAF=4" "RT_BVH_LEAF=5" "RT_BVH_LEAF=7"; do
+  echo "== $v"; env $v timeout -k 10 120 python -u tools/exp_drt.py 4 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k:(round(v,2) if isinstance(v,float) else v) for k,v in d.items() if k in ('ms_per_frame','mrays_per_s','lane_closest_ms','lane_any_ms','closest_ms','any_ms','path_ms','path_roots')})" || exit $?
 done
-RT_KNN_TRACE=1 timeout -k 10 400 python -u tools/exp_pframe.py full 2> gpurun_out/knn_trace.txt | tail -n 1 | cut -c1-100; grep "kNN call: 1000000" gpurun_out/knn_trace.txt | sort -t, -k5 | tail -n 12
