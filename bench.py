@@ -188,6 +188,9 @@ def make_roofline(workload, kernel, avg_ms, units_per_launch, alg_bytes, wave_by
                algorithmic_bytes_per_launch=alg_bytes, algorithmic_gbs=alg_bytes / t / 1e9,
                wave_fetched_bytes_per_launch=wave_bytes,
                hbm_traffic_gbs=(traffic / t / 1e9) if traffic else None,
+               # the traffic itself against the peak (lines moved, useful or not): the 200 M-photon estimate and the path kernel
+               # are limited by it (scattered 64-byte records / 128-byte lines), whatever `frac` says about the useful bytes
+               hbm_traffic_frac=(traffic / t / 1e9 / HBM_PEAK_GBS) if traffic else None,
                fractions={k: v[0] / v[1] for k, v in fr.items()},
                l2_hit_rate=c.get("l2_hit_rate") if c else None,
                wait_inst_fraction=(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]) if c and c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_INST_ANY") else None,
