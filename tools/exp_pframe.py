@@ -16,4 +16,6 @@ def find(o, path=""):
     elif isinstance(o, (np.ndarray, np.generic)):
         print("numpy value at", path, type(o), file=sys.stderr)
 find(r)
-print(bench.dumps({k: r[k] for k in ("value", "lookups_per_s", "ms_per_frame", "knn_lookups", "parity")}))
+rf = r["roofline"]
+print(bench.dumps(dict({k: r[k] for k in ("value", "lookups_per_s", "ms_per_frame", "knn_lookups")}, one_stream_ms=r.get("ms_per_frame_on_one_stream"), knn_ms=rf.get("ms_per_frame_in_the_estimate"),
+                       waves=rf.get("waves"), walk_nodes_per_wave=rf.get("walk_nodes_per_wave"), inserted_per_wave=rf.get("inserted_per_wave"), redo=rf.get("strict_redo_queries"), parity=r["parity"]["parity_sample_ok"])))
