@@ -302,6 +302,46 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             v.lane_step = 1;
         }
     }
+    // ... and the tables for walks that start at the origin's leaf (trace_device.h: bvh_lane_start_from): one pre-order pass
+    // over the compact nodes
+    {
+        const char* e = getenv("RT_LANE_ORIGIN");
+        if (!rc && v.lane_step && (!e || atoi(e) != 0) && nbvh > 0) {
+            const auto& nd = flat.bvh_c32;
+            std::vector<int32_t> up((size_t)nbvh + 4, nbvh), parent((size_t)nbvh, -1), prim_start(ptype.size() * 4, -1);
+            for (int32_t i = 0; i < nbvh; ++i) {
+                const DevBvhNode32& n = nd[(size_t)i];
+                const int32_t par = parent[(size_t)i];
+                if (n.link >> 31) {
+                    const uint32_t t0 = n.link & 0x7fffffffu, cnt = (n.sq >> 1) & 7u;
+                    for (uint32_t t = t0; t < t0 + cnt; ++t) {
+                        const int32_t p = flat.bvh_tris[t].prim;
+                        if (p < 0 || (size_t)p >= ptype.size()) continue;
+                        int32_t sib = nbvh;                                    // the leaf's own sibling: the walk's second range
+                        if (par >= 0) {
+                            const int32_t pl = par + 1;
+                            sib = (i == pl) ? pl + 1 : pl;                     // (a leaf is one node: its right sibling follows it)
+                        }
+                        int32_t* q = &prim_start[4 * (size_t)p];
+                        q[0] = i; q[1] = i + 1; q[2] = sib; q[3] = 0;
+                    }
+                } else {
+                    const int32_t left = i + 1;
+                    const int32_t right = (nd[(size_t)left].link >> 31) ? left + 1 : (int32_t)nd[(size_t)left].link;
+                    parent[(size_t)left] = parent[(size_t)right] = i;
+                    // after a child's subtree a climbing walk goes on at the sibling of i (i = the child's parent)
+                    int32_t sib = nbvh;
+                    if (par >= 0) {
+                        const int32_t pl = par + 1;
+                        sib = (i == pl) ? ((nd[(size_t)pl].link >> 31) ? pl + 1 : (int32_t)nd[(size_t)pl].link) : pl;
+                    }
+                    up[(size_t)left] = up[(size_t)right] = sib;
+                }
+            }
+            rc = upload(s, up, &v.bvh_up);
+            if (!rc) rc = upload(s, prim_start, &v.prim_start);
+        }
+    }
     if (const char* e = getenv("RT_LANE_STEP")) v.lane_step = (atoi(e) != 0 && v.bvh_tri_reach) ? 1 : 0;
     if (const char* e = getenv("RT_LANE_REFILL_BATCH")) { const int b = atoi(e); v.lane_refill_batch = b < 1 ? 1 : (b > 64 ? 64 : b); }
     if (const char* e = getenv("RT_LANE_CHUNK")) { const int b = atoi(e); v.lane_chunk = b < 16 ? 16 : (b > 4096 ? 4096 : b); }

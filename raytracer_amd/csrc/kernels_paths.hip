@@ -30,8 +30,8 @@
 
 #define PATH_MAX_LIGHTS 32
 
-struct PathStackEntry { float o[6]; float w, nr; uint32_t code; int32_t depth; };     // 40 B: a pending child
-static_assert(sizeof(PathStackEntry) == 40, "PathStackEntry must be 40 bytes");
+struct PathStackEntry { float o[6]; float w, nr; uint32_t code; int32_t depth; int32_t src; };     // 44 B: a pending child (src: the triangle it starts on)
+static_assert(sizeof(PathStackEntry) == 44, "PathStackEntry must be 44 bytes");
 
 struct PathArgs {
     const rt_ray* rays; const int32_t* pix; const float* w; const float* nr; const uint32_t* code;   // the depth-P queue
@@ -45,6 +45,7 @@ struct PathArgs {
                                          // children; [5] closest-hit rays, [6] shadow rays of THIS kernel
     unsigned long long* work;            // COUNT: [0] box tests, [1] triangle records of the closest walks; [4], [5] of the shadow walks
     int32_t batch;                       // events run when this many lanes wait (or no lane walks)
+    const int32_t* src;                  // NULL, or per queue entry the triangle its ray starts on (-1: unknown)
     const int32_t* order;                // NULL, or the order in which queue entries are handed to lanes (rtk_ray_order); sums go to the entries' own slots
 };
 
@@ -64,6 +65,7 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
     float ar = 0.f, ag = 0.f, ab = 0.f;
     // the ray at hand
     float w = 0.f, nr = 1.f; uint32_t code = 0u; int depth = 0;
+    int src = -1;                                 // the triangle the ray at hand starts on (-1: unknown): its walk starts at that leaf
     BvhLaneWalk wk; wk.i = nn; wk.far_limit = 0.f; wk.nodes = sc.bvh_oct[0];
     wk.r = Rayf{0, 0, 0, 0, 0, 1};
     wk.bc = BvhConsts{1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -127,11 +129,11 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                         if (f0) {                                        // the reflected child goes first: this one waits
                             PathStackEntry* e = stk + 64 * (size_t)sp;
                             e->o[0] = o6[0]; e->o[1] = o6[1]; e->o[2] = o6[2]; e->o[3] = o6[3]; e->o[4] = o6[4]; e->o[5] = o6[5];
-                            e->w = w * m.refract; e->nr = m.Nr; e->code = child_code(code, 1u); e->depth = depth + 1;
+                            e->w = w * m.refract; e->nr = m.Nr; e->code = child_code(code, 1u); e->depth = depth + 1; e->src = c.prim;
                             ++sp;
                         } else {
                             wk.r = Rayf{o6[0], o6[1], o6[2], o6[3], o6[4], o6[5]};
-                            w = w * m.refract; nr = m.Nr; code = child_code(code, 1u); depth = depth + 1;
+                            w = w * m.refract; nr = m.Nr; code = child_code(code, 1u); depth = depth + 1; src = c.prim;
                             mode = M_START;
                         }
                     }
@@ -139,7 +141,7 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                         reflect_child(c, a.glossy, drt, a.seed, px, code, o6);
                         ++n_refl;
                         wk.r = Rayf{o6[0], o6[1], o6[2], o6[3], o6[4], o6[5]};
-                        w = w * m.reflect; code = child_code(code, 0u); depth = depth + 1;      // nr stays (hw4.cpp:903)
+                        w = w * m.reflect; code = child_code(code, 0u); depth = depth + 1; src = c.prim;      // nr stays (hw4.cpp:903)
                         mode = M_START;
                     }
                 }
@@ -150,7 +152,7 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                     --sp;
                     const PathStackEntry* e = stk + 64 * (size_t)sp;
                     wk.r = Rayf{e->o[0], e->o[1], e->o[2], e->o[3], e->o[4], e->o[5]};
-                    w = e->w; nr = e->nr; code = e->code; depth = e->depth;
+                    w = e->w; nr = e->nr; code = e->code; depth = e->depth; src = e->src;
                     mode = M_START;
                 } else {
                     a.contrib[3 * idx] = ar; a.contrib[3 * idx + 1] = ag; a.contrib[3 * idx + 2] = ab;
@@ -172,7 +174,7 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                                 idx = my; px = p; ar = ag = ab = 0.f; sp = 0;
                                 wk.r = load_ray(a.rays, my);
                                 w = a.w ? a.w[my] : 1.0f; nr = a.nr ? a.nr[my] : a.start_nr; code = a.code ? a.code[my] : 0u;
-                                depth = a.depth0;
+                                depth = a.depth0; src = a.src ? a.src[my] : -1;
                                 mode = M_START;
                             }
                         }
@@ -195,7 +197,10 @@ k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
                 fresh = true; occ = false;
                 best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
                 lane_cursor_reset(cu);
-                if (bvh_fit(aux)) bvh_lane_start(sc, wk.r, aux, shadow ? 1e9f : 0.f, wk);      // HW4's IsInShadow has no far limit (Q4)
+                if (bvh_fit(aux)) {                                                            // HW4's IsInShadow has no far limit (Q4)
+                    if (STEP) bvh_lane_start_from(sc, wk.r, aux, shadow ? 1e9f : 0.f, wk, shadow ? c.prim : src);
+                    else bvh_lane_start(sc, wk.r, aux, shadow ? 1e9f : 0.f, wk);
+                }
                 else { unfit = true; wk.i = nn; wk.far_limit = shadow ? 1e9f : 0.f; }
                 mode = shadow ? M_SHADOW : M_CLOSEST;
             }
@@ -285,7 +290,7 @@ size_t rtk_paths_stack_bytes(int64_t n, int depth0, int max_depth) {
 hipError_t rtk_paths(const DevSceneView& sc0, const rt_ray* rays, const int32_t* pix, const float* w, const float* nr,
                      const uint32_t* code, int64_t n, int depth0, int max_depth, float eps_f, float ambient, const float eye[3],
                      float start_nr, uint64_t seed, float light_radius, float glossy, float* contrib, void* stack,
-                     unsigned long long* counters, unsigned long long* work, hipStream_t st, const int32_t* order) {
+                     unsigned long long* counters, unsigned long long* work, hipStream_t st, const int32_t* order, const int32_t* src) {
     if (n <= 0) return hipSuccess;
     DevSceneView sc = sc0;
     hipError_t e = rtk_next_ray_counter(sc, st);         // this launch's eight range counters, zeroed on `st`
@@ -296,7 +301,7 @@ hipError_t rtk_paths(const DevSceneView& sc0, const rt_ray* rays, const int32_t*
     a.eps_f = eps_f; a.ambient = ambient; a.eye[0] = eye[0]; a.eye[1] = eye[1]; a.eye[2] = eye[2]; a.start_nr = start_nr;
     a.seed = seed; a.light_radius = light_radius; a.glossy = glossy; a.contrib = contrib;
     a.stack = (PathStackEntry*)stack; a.stack_depth = (max_depth - depth0 + 1) > 1 ? (max_depth - depth0 + 1) : 1;
-    a.counters = counters; a.work = work; a.batch = batch; a.order = order;
+    a.counters = counters; a.work = work; a.batch = batch; a.order = order; a.src = src;
     const unsigned grid = (unsigned)paths_waves(n);
     if (sc.lane_step) {
         if (work) hipLaunchKernelGGL((k_paths_bvh_lanes<true, true>), dim3(grid), dim3(64), 0, st, sc, a);

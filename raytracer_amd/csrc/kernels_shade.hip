@@ -216,7 +216,7 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         const uint8_t* __restrict__ flags, int64_t nflags, const uint32_t* __restrict__ block_offsets,
         rt_ray* __restrict__ orays, int32_t* __restrict__ opix, float* __restrict__ oweight, float* __restrict__ onr,
         unsigned int* __restrict__ kind_pairs, const uint32_t* __restrict__ code, uint32_t* __restrict__ ocode,
-        uint64_t seed, float glossy, uint8_t* __restrict__ ooct) {
+        uint64_t seed, float glossy, uint8_t* __restrict__ ooct, int32_t* __restrict__ osrc) {
     __shared__ uint32_t wsum[SCAN_BLOCK / 64];
     __shared__ unsigned int kinds[2];
     if (threadIdx.x < 2) kinds[threadIdx.x] = 0;
@@ -257,6 +257,7 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         opix[pos] = pix[i];
         if (ooct) ooct[pos] = (uint8_t)((o[3] < 0.f ? 1u : 0u) | (o[4] < 0.f ? 2u : 0u) | (o[5] < 0.f ? 4u : 0u));   // k_ray_keys' octant
         if (ocode) ocode[pos] = child_code(code[i], (unsigned)(slot & 1));
+        if (osrc) osrc[pos] = c.prim;                                       // the triangle the child starts on (RaySrc)
         ++pos;
     }
     if (nrefl) atomicAdd(&kinds[0], (unsigned)nrefl);
@@ -420,7 +421,7 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
                                 const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
                                 float* onr, unsigned long long* counters, const uint32_t* code, uint32_t* ocode,
-                                uint64_t seed, float glossy, hipStream_t st, uint8_t* ooct) {
+                                uint64_t seed, float glossy, hipStream_t st, uint8_t* ooct, int32_t* osrc) {
     if (nflags <= 0) return hipSuccess;
     const int64_t nb = rtk_scan_blocks_needed(nflags);
     hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, nflags, block_sums);
@@ -428,7 +429,7 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
     // block_sums: [nb] offsets, then (256-byte aligned) [nb][2] per-block child counts by kind
     unsigned int* kind_pairs = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(block_sums) + (((size_t)nb * 4 + 16 + 255) & ~(size_t)255));
     hipLaunchKernelGGL(k_spawn, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, sc, rays, hits, pix, weight, nr_in, flags,
-                       nflags, block_sums, orays, opix, oweight, onr, kind_pairs, code, ocode, seed, glossy, ooct);
+                       nflags, block_sums, orays, opix, oweight, onr, kind_pairs, code, ocode, seed, glossy, ooct, osrc);
     hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, kind_pairs, nb, counters + 3);      // [3] reflect, [4] refract children
     return hipGetLastError();
 }

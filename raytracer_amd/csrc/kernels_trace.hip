@@ -205,7 +205,8 @@ k_trace_any_bvh_lanes(DevSceneView sc, const rt_ray* __restrict__ rays, const in
 template <bool ANY>
 __device__ __forceinline__ void bvh_lanes_step(const DevSceneView& sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
                                                const float* __restrict__ tmax, int64_t n, float eps_f,
-                                               rt_hit* __restrict__ out, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order) {
+                                               rt_hit* __restrict__ out, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order,
+                                               const RaySrc src) {
     const int lane = threadIdx.x & 63;
     const int nn = sc.nbvh;
     const bool use_tmax = tmax != nullptr;
@@ -247,7 +248,8 @@ __device__ __forceinline__ void bvh_lanes_step(const DevSceneView& sc, const rt_
                     if (bvh_fit(aux)) {
                         idx = my; have = true; occ = false; fresh = true;
                         best.len = 1e9f; best.prim = -1; best.px = best.py = best.pz = 0.f; best.rank = 0x7fffffff;
-                        bvh_lane_start(sc, r, aux, ANY ? (use_tmax ? tmax[my] : 1e9f) : 0.f, wk);
+                        const int from = src.base ? *reinterpret_cast<const int32_t*>(src.base + (my / src.div) * (int64_t)src.stride) : -1;
+                        bvh_lane_start_from(sc, r, aux, ANY ? (use_tmax ? tmax[my] : 1e9f) : 0.f, wk, from);
                         lane_cursor_reset(cu);
                     }
                 }
@@ -269,14 +271,15 @@ __device__ __forceinline__ void bvh_lanes_step(const DevSceneView& sc, const rt_
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_trace_closest_bvh_step(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                         int64_t n, float eps_f, rt_hit* __restrict__ out, const int32_t* __restrict__ order) {
-    bvh_lanes_step<false>(sc, rays, active, nullptr, n, eps_f, out, nullptr, order);
+                         int64_t n, float eps_f, rt_hit* __restrict__ out, const int32_t* __restrict__ order, RaySrc src) {
+    bvh_lanes_step<false>(sc, rays, active, nullptr, n, eps_f, out, nullptr, order, src);
 }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_trace_any_bvh_step(DevSceneView sc, const rt_ray* __restrict__ rays, const int32_t* __restrict__ active,
-                     const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order) {
-    bvh_lanes_step<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded, order);
+                     const float* __restrict__ tmax, int64_t n, float eps_f, uint8_t* __restrict__ occluded, const int32_t* __restrict__ order,
+                     RaySrc src) {
+    bvh_lanes_step<true>(sc, rays, active, tmax, n, eps_f, nullptr, occluded, order, src);
 }
 
 // the build's own hierarchy instead of the reference's tree (trace_device.h: traverse_bvh)
@@ -529,8 +532,9 @@ static inline unsigned lanes_grid(const DevSceneView& sc, int64_t n) {
 }
 
 hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
-                             float eps_f, int fast, rt_hit* d_out, hipStream_t st, const int32_t* d_order) {
+                             float eps_f, int fast, rt_hit* d_out, hipStream_t st, const int32_t* d_order, const RaySrc* src) {
     if (n <= 0) return hipSuccess;
+    const RaySrc from = (src && src->base && src->div > 0) ? *src : RaySrc{nullptr, 0, 1};
     if (fast == 3) {
         hipLaunchKernelGGL(k_trace_closest_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, n, eps_f, d_out, d_order);
         return hipGetLastError();
@@ -541,7 +545,7 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            if (sc.lane_step) hipLaunchKernelGGL(k_trace_closest_bvh_step, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
+            if (sc.lane_step) hipLaunchKernelGGL(k_trace_closest_bvh_step, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order, from);
             else hipLaunchKernelGGL(k_trace_closest_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, n, eps_f, d_out, d_order);
         }
         hipLaunchKernelGGL(k_trace_closest_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, n, eps_f, lanes, d_out);
@@ -552,8 +556,9 @@ hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const
 }
 
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
-                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st, const int32_t* d_order) {
+                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st, const int32_t* d_order, const RaySrc* src) {
     if (n <= 0) return hipSuccess;
+    const RaySrc from = (src && src->base && src->div > 0) ? *src : RaySrc{nullptr, 0, 1};
     if (fast == 3) {
         hipLaunchKernelGGL(k_trace_any_bvh, dim3(grid_for(n, 256)), dim3(256), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
         return hipGetLastError();
@@ -564,7 +569,7 @@ hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int
             DevSceneView scl = sc;
             hipError_t e = next_ray_counter(scl, st);
             if (e != hipSuccess) return e;
-            if (sc.lane_step) hipLaunchKernelGGL(k_trace_any_bvh_step, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
+            if (sc.lane_step) hipLaunchKernelGGL(k_trace_any_bvh_step, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order, from);
             else hipLaunchKernelGGL(k_trace_any_bvh_lanes, dim3(lanes_grid(sc, n)), dim3(64), 0, st, scl, d_rays, d_active, d_tmax, n, eps_f, d_occ, d_order);
         }
         hipLaunchKernelGGL(k_trace_any_lane, dim3(grid_for(n, 64)), dim3(64), 0, st, sc, d_rays, d_active, d_tmax, n, eps_f, lanes, d_occ);

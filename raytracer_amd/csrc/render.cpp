@@ -16,9 +16,9 @@ enum Slot {   // scratch slots of rt_scene used by the renderer
     S_TILES = 3, S_RAYS0, S_PIX0, S_HITS, S_SRAYS, S_SACTIVE, S_OCC, S_CONTRIB, S_FLAGS, S_BSUMS,
     S_QA_RAYS, S_QA_PIX, S_QA_W, S_QA_NR, S_QB_RAYS, S_QB_PIX, S_QB_W, S_QB_NR, S_ACCUM, S_HITANY, S_COUNTERS, S_PAIRS, S_WORK, S_W0, S_CODE0, S_PIXLIST, S_QA_CODE, S_QB_CODE, S_ORDER_C, S_ORDER_A,
     S_HITS1, S_SRAYS1, S_SACTIVE1, S_HITS2, S_SRAYS2, S_SACTIVE2, S_QC_RAYS, S_QC_PIX, S_QC_W, S_QC_NR, S_QC_CODE,
-    S_PATH_CONTRIB, S_PATH_STACK, S_Q_OCT
+    S_PATH_CONTRIB, S_PATH_STACK, S_Q_OCT, S_QA_SRC, S_QB_SRC, S_QC_SRC
 };
-static_assert(S_Q_OCT < RT_NSCRATCH, "not enough scratch slots");
+static_assert(S_QC_SRC < RT_NSCRATCH, "not enough scratch slots");
 
 #define HIPCHK(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return rt_hipfail(e__, what); } while (0)
 #define RTCHK(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -194,7 +194,12 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
     static const int HITS_SLOT[3] = {S_HITS, S_HITS1, S_HITS2}, SRAYS_SLOT[3] = {S_SRAYS, S_SRAYS1, S_SRAYS2},
                      SACT_SLOT[3] = {S_SACTIVE, S_SACTIVE1, S_SACTIVE2};
     static const int Q_RAYS[3] = {S_QA_RAYS, S_QB_RAYS, S_QC_RAYS}, Q_PIX[3] = {S_QA_PIX, S_QB_PIX, S_QC_PIX}, Q_W[3] = {S_QA_W, S_QB_W, S_QC_W},
-                     Q_NR[3] = {S_QA_NR, S_QB_NR, S_QC_NR}, Q_CODE[3] = {S_QA_CODE, S_QB_CODE, S_QC_CODE};
+                     Q_NR[3] = {S_QA_NR, S_QB_NR, S_QC_NR}, Q_CODE[3] = {S_QA_CODE, S_QB_CODE, S_QC_CODE},
+                     Q_SRC[3] = {S_QA_SRC, S_QB_SRC, S_QC_SRC};
+    // per-lane walks start at the leaf of the triangle their ray starts on (trace_device.h: bvh_lane_start_from): the children
+    // of a queue carry that triangle beside them when the pass that takes them walks per lane
+    const int32_t* q_src = nullptr;
+    const bool origin_walks = s->view.prim_start != nullptr;
     hipEvent_t order_done = nullptr;                    // the second stream has ordered its shadow rays (rtk_ray_order)
     const uint8_t* q_oct = nullptr;                     // the queue's direction octants, one byte per ray (k_spawn), or NULL
     static const bool oct_partition = [] { const char* e = getenv("RT_OCT_PARTITION"); return e ? atoi(e) != 0 : true; }();
@@ -226,7 +231,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
                 HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_p, st), "ray order");
             }
             HIPCHK(rtk_paths(view, q_rays, q_pix, q_w, q_nr, q_code, n, depth, p->max_depth, s->eps_f, p->ambient_intensity, cam->center,
-                             p->start_nr, p->seed, p->light_radius, p->glossy, (float*)pc, stk, d_ctr, d_work ? d_work + 16 : nullptr, st, order_p),
+                             p->start_nr, p->seed, p->light_radius, p->glossy, (float*)pc, stk, d_ctr, d_work ? d_work + 16 : nullptr, st, order_p, q_src),
                    "k_paths_bvh_lanes");
             RTCHK(mark(st)); RTCHK(mark(st)); RTCHK(mark(st));
             // the entries' sums join the pixels after every earlier pass's (the accumulation stream keeps pass order)
@@ -284,7 +289,8 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             HIPCHK(rtk_ray_order(q_rays, q_pix, n, s->bvh_lo, s->bvh_hi, ow, &order_c, st, RT_ORDER_OCTANT), "ray order");
         }
         if (order_done) { HIPCHK(hipStreamWaitEvent(st, order_done, 0), "hipStreamWaitEvent"); order_done = nullptr; }
-        HIPCHK(rtk_trace_closest(view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c), "k_trace_closest");
+        const RaySrc src_c = {(const char*)q_src, 4, 1}, src_a = {origin_walks && pass_mode == 2 ? (const char*)hits : nullptr, (int32_t)sizeof(rt_hit), L > 0 ? L : 1};
+        HIPCHK(rtk_trace_closest(view, q_rays, q_pix, n, s->eps_f, pass_mode, (rt_hit*)hits, st, order_c, &src_c), "k_trace_closest");
         RTCHK(mark(st));
         HIPCHK(rtk_shade_flags(s->view, q_rays, (const rt_hit*)hits, q_pix, n, spawn ? 1 : 0, depth == 0 ? 1 : 0,
                                (uint8_t*)flags, (rt_ray*)srays, (int32_t*)sact, depth == 0 ? d_hit_ids : nullptr,
@@ -306,7 +312,7 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
                     if (!order_done) return rt_hipfail(err, "event");
                 }
             }
-            HIPCHK(rtk_trace_any(view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, sb, order_a), "k_trace_any");
+            HIPCHK(rtk_trace_any(view, (const rt_ray*)srays, (const int32_t*)sact, nullptr, n * L, s->eps_f, pass_mode, (uint8_t*)occ, sb, order_a, &src_a), "k_trace_any");
         }
         RTCHK(mark(sb));
         if (d_work) {
@@ -351,14 +357,19 @@ int render_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, uint8_t* 
             const bool next_paths = false;      // (the path kernel takes its queue in queue order; whether it runs is known only with the child count)
             if (oct_partition && next_mode == 3 && !next_paths && s->view.nbvh > 0 && !sorted) RTCHK(s->scratch(S_Q_OCT, (size_t)n * 2, &ooct));
         }
+        void* osrc = nullptr;
+        {
+            const int next_lane = ((s->fast == 1 || s->fast == 3) && depth + 1 >= s->lane_depth) ? 1 : 0;
+            if (origin_walks && (next_lane || (use_paths && depth + 1 == s->path_depth))) RTCHK(s->scratch(Q_SRC[qo], (size_t)n * 2 * 4, &osrc));
+        }
         HIPCHK(rtk_compact_children(s->view, q_rays, (const rt_hit*)hits, q_pix, q_w, nr_in, (const uint8_t*)flags, 2 * n,
                                     (uint32_t*)bsums, d_total, (rt_ray*)orays, (int32_t*)opix, (float*)ow, (float*)onr,
-                                    d_ctr, q_code, (uint32_t*)ocode, p->seed, p->glossy, st, (uint8_t*)ooct), "compact children");
+                                    d_ctr, q_code, (uint32_t*)ocode, p->seed, p->glossy, st, (uint8_t*)ooct, (int32_t*)osrc), "compact children");
         uint32_t total = 0;
         HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st), "read child count");
         HIPCHK(hipStreamSynchronize(st), "sync");
         q_rays = (const rt_ray*)orays; q_pix = (const int32_t*)opix; q_w = (const float*)ow; q_nr = (const float*)onr;
-        q_code = (const uint32_t*)ocode; q_oct = (const uint8_t*)ooct;
+        q_code = (const uint32_t*)ocode; q_oct = (const uint8_t*)ooct; q_src = (const int32_t*)osrc;
         n = (int64_t)total;
     }
     if (b_last) HIPCHK(hipStreamWaitEvent(st, b_last, 0), "hipStreamWaitEvent");       // the frame needs every pass's sum

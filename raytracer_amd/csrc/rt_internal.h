@@ -166,6 +166,9 @@ struct DevSceneView {       // passed by value to kernels
     int32_t lane_refill_batch;          // ... idle lanes claim new rays when this many wait (or no lane walks)
     int32_t lane_chunk;                 // ... a wave claims at most this many rays with one atomic
     int32_t lane_acc_batch;             // ... pending candidates take their reachability test when this many wait (or no lane can step)
+    const int32_t* bvh_up;              // single-step walk from the ORIGIN's leaf (trace_device.h: bvh_lane_start_from): [node] the sibling of
+                                        // the node's parent -- where a walk that climbs goes on after the node's subtree -- or nbvh; 4 entries of padding
+    const int32_t* prim_start;          // [prim][4]: the leaf holding triangle `prim`, the node after it, the leaf's sibling (or nbvh), 0; leaf -1 = none
     const DevRefLeaf* bvh_ref_leaf;     // the reference leaves holding triangle t, by rising rank
     const int32_t* ref_parent;          // parent of reference node i (layout 7), -1 = a root
     const float* ref_chain_box;         // [node][6]: lo, hi of the intersection of the boxes on node i's chain (NaN lo[0]: none)
@@ -242,10 +245,16 @@ float rt_float_above(double t);
 // kernel launchers (defined in the .hip files)
 #include <hip/hip_runtime_api.h>
 // d_order (per-lane kernels only): the order in which rays are handed to lanes (rtk_ray_order), NULL = index order
+// RaySrc: where the triangle ray i STARTS ON is written, for the per-lane kernels' walks from the origin's leaf
+// (trace_device.h: bvh_lane_start_from): the int32 at base + (i / div) * stride; base NULL = not known.  The children of a
+// queue carry it in an array of their own (stride 4, div 1), the shadow rays of a pass read their hit's (rt_hit, div = lights).
+struct RaySrc { const char* base; int32_t stride, div; };
 hipError_t rtk_trace_closest(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, int64_t n,
-                             float eps_f, int fast, rt_hit* d_out, hipStream_t st, const int32_t* d_order = nullptr);
+                             float eps_f, int fast, rt_hit* d_out, hipStream_t st, const int32_t* d_order = nullptr,
+                             const RaySrc* src = nullptr);
 hipError_t rtk_trace_any(const DevSceneView& sc, const rt_ray* d_rays, const int32_t* d_active, const float* d_tmax,
-                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st, const int32_t* d_order = nullptr);
+                         int64_t n, float eps_f, int fast, uint8_t* d_occ, hipStream_t st, const int32_t* d_order = nullptr,
+                         const RaySrc* src = nullptr);
 size_t rtk_ray_order_workspace(int64_t n);
 // what rtk_ray_order sorts by: the whole key (cell of the origin, direction octant, finer Morton bits), the octant alone
 // (a stable partition), or the cell alone
@@ -277,7 +286,8 @@ size_t rtk_paths_stack_bytes(int64_t n, int depth0, int max_depth);
 hipError_t rtk_paths(const DevSceneView& sc, const rt_ray* rays, const int32_t* pix, const float* w, const float* nr,
                      const uint32_t* code, int64_t n, int depth0, int max_depth, float eps_f, float ambient, const float eye[3],
                      float start_nr, uint64_t seed, float light_radius, float glossy, float* contrib, void* stack,
-                     unsigned long long* counters, unsigned long long* work, hipStream_t st, const int32_t* order = nullptr);
+                     unsigned long long* counters, unsigned long long* work, hipStream_t st, const int32_t* order = nullptr,
+                     const int32_t* src = nullptr);
 
 // kernels_shade.hip
 hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_hit* hits, const int32_t* pix, int64_t n,
@@ -294,7 +304,7 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
                                 const float* weight, const float* nr_in, const uint8_t* flags, int64_t nflags,
                                 uint32_t* block_sums, uint32_t* d_total, rt_ray* orays, int32_t* opix, float* oweight,
                                 float* onr, unsigned long long* counters, const uint32_t* code, uint32_t* ocode,
-                                uint64_t seed, float glossy, hipStream_t st, uint8_t* ooct = nullptr);
+                                uint64_t seed, float glossy, hipStream_t st, uint8_t* ooct = nullptr, int32_t* osrc = nullptr);
 // ooct (optional): one byte per child, the octant of its direction; rtk_octant_order turns them into the order in which a
 // wave-synchronous pass takes the queue (a stable partition by octant)
 size_t rtk_octant_order_workspace(int64_t n);

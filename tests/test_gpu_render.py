@@ -330,6 +330,46 @@ def test_mesh_1m_distributed_ray_tracing_vs_oracle(mesh1m):
     assert st.rays_reflect > 1000 and st.passes >= 3 and st.path_launches == 1 and st.path_closest_rays > 100
 
 
+def test_walks_from_the_origins_leaf_find_what_walks_from_the_root_find(mesh1m, monkeypatch):
+    """Per-lane walks of rays that start ON a triangle (shadow rays, reflected / refracted children) begin at that triangle's
+    leaf and climb -- the leaf, its sibling's subtree, the sibling of every ancestor -- instead of descending from the root
+    through ~20 boxes that contain the origin (trace_device.h: bvh_lane_start_from; RT_LANE_ORIGIN=0 at scene creation: off).
+    An order of visits, not of results: on the 1 M-triangle scene under the drt_1m samplers at 480x270 x 4 spp, with the
+    per-lane kernels from depth 1 on (path kernel from depth 1, and passes 1-2 per lane + path kernel from 3), the ray counts
+    are equal and the radiance is the same bits with the tables and without, and it is the oracle's (<= 1e-4 * max(1, |L|) on
+    every pixel); the box tests counted go down, so the walks did start at the leaves."""
+    sd, g, o = mesh1m
+    res = (480, 270)
+    kw = dict(spp=4, lens_radius=0.01, focal_distance=1.3, light_radius=0.5, glossy=0.05, seed=3)
+    cam = host.camera_for(sd, res)
+    monkeypatch.setenv("RT_LANE_ORIGIN", "0")
+    g0 = host.Scene(sd)
+    monkeypatch.delenv("RT_LANE_ORIGIN")
+    orgb, oids, orad = o.render_whitted(ol.oracle_camera(sd.eye, sd.view, sd.fov, *res), host.default_params("hw4", **kw), want_radiance=True)
+    orad = orad.reshape(res[1], res[0], 3)
+    try:
+        for pd, ld in ((1, 2), (3, 1)):
+            got = []
+            for sc in (g, g0):
+                abi.check(sc.L.rt_scene_set_option(sc.h, abi.RT_OPT_PATH_DEPTH, pd))
+                abi.check(sc.L.rt_scene_set_option(sc.h, abi.RT_OPT_LANE_DEPTH, ld))
+                rgb, ids, st = sc.render(cam, host.default_params("hw4", count_work=1, **kw), want_ids=True)
+                rad, _ = sc.render_radiance(cam, host.default_params("hw4", **kw))
+                got.append((rad, (st.rays_primary, st.rays_reflect, st.rays_refract, st.rays_shadow), ids,
+                            int(st.path_work[0]) + int(st.path_work[2])))        # box tests of the path kernel's closest and shadow walks
+            assert got[0][1] == got[1][1] and got[0][1][1] > 100000, (pd, got[0][1], got[1][1])
+            assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][2], oids)
+            assert np.array_equal(got[0][0], got[1][0]), (pd, int((got[0][0] != got[1][0]).any(-1).sum()))
+            bad = (np.abs(got[0][0] - orad) > 1e-4 * np.maximum(1.0, np.abs(orad))).any(-1)
+            assert bad.sum() == 0, (pd, int(bad.sum()))
+            assert got[0][3] < 0.95 * got[1][3], (pd, got[0][3], got[1][3])
+    finally:
+        for sc in (g, g0):
+            abi.check(sc.L.rt_scene_set_option(sc.h, abi.RT_OPT_PATH_DEPTH, 3))
+            abi.check(sc.L.rt_scene_set_option(sc.h, abi.RT_OPT_LANE_DEPTH, 2))
+        g0.close()
+
+
 def test_path_kernel_traces_the_rays_the_passes_trace(monkey_sd):
     """RT_OPT_PATH_DEPTH: the rays of recursion depth >= the option are followed through their whole subtrees by one
     persistent kernel (kernels_paths.hip) instead of one pass of kernels per depth.  Every ray gets the same hit, the same
