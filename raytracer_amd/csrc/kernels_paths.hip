@@ -51,8 +51,11 @@ struct PathArgs {
 
 enum PathMode { M_IDLE = 0, M_CLOSEST, M_SHADOW, M_SHADOW_SETUP, M_SHADE, M_NEXT, M_START };
 
+#ifndef RT_PATH_WPE
+#define RT_PATH_WPE 4
+#endif
 template <bool COUNT, bool STEP>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PATH_WPE, 8)))
 k_paths_bvh_lanes(DevSceneView sc, PathArgs a) {
     const int lane = threadIdx.x & 63;
     const int nn = sc.nbvh;

@@ -38,17 +38,17 @@ __device__ __forceinline__ void block_count2(unsigned long long* ctr /* per-bloc
 }
 
 // sums the per-block pairs written by block_count2 into counters[0], counters[1]
-extern "C" __global__ void __launch_bounds__(1024)
+extern "C" __global__ void __launch_bounds__(256)
 k_reduce_pairs(const unsigned int* __restrict__ pairs, int64_t nblocks, unsigned long long* __restrict__ counters) {
-    __shared__ unsigned long long red[2][16];
+    __shared__ unsigned long long red[2][4];                           // 256 lanes: four waves find a place on a busy chip, sixteen wait for one
     unsigned long long a = 0, b = 0;
-    for (int64_t i = threadIdx.x; i < nblocks; i += 1024) { a += pairs[2 * i]; b += pairs[2 * i + 1]; }
+    for (int64_t i = threadIdx.x; i < nblocks; i += 256) { const uint2 v = reinterpret_cast<const uint2*>(pairs)[i]; a += v.x; b += v.y; }
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x < 2) {
         unsigned long long t = 0;
-        for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
+        for (int w = 0; w < 4; ++w) t += red[threadIdx.x][w];
         counters[threadIdx.x] += t;
     }
 }
@@ -182,28 +182,33 @@ k_scan_count(const uint8_t* __restrict__ flags, int64_t n, uint32_t* __restrict_
     if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += red[w]; block_sums[blockIdx.x] = t; }
 }
 
-// single block: exclusive scan of block_sums in place, total -> *total
-extern "C" __global__ void __launch_bounds__(1024)
+// single block: exclusive scan of block_sums in place, total -> *total.  256 lanes x 16 consecutive entries per trip, wave
+// scans by shuffles: a block of four waves finds a place on a chip that a traversal kernel of the other stream has filled
+// (the 1024-lane block this replaces waited 0.2 - 0.5 ms for sixteen free wave slots on one CU, three times per frame)
+#define SCANB_ITEMS 16
+extern "C" __global__ void __launch_bounds__(256)
 k_scan_blocks(uint32_t* __restrict__ block_sums, int64_t nblocks, uint32_t* __restrict__ total) {
-    __shared__ uint32_t buf[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < nblocks; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? block_sums[i] : 0;
-        buf[threadIdx.x] = v;
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t carry = 0;                                                    // (every lane keeps the same running total)
+    for (int64_t base = 0; base < nblocks; base += 256 * SCANB_ITEMS) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * SCANB_ITEMS;
+        uint32_t v[SCANB_ITEMS];
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < SCANB_ITEMS; ++k) { v[k] = i0 + k < nblocks ? block_sums[i0 + k] : 0u; s += v[k]; }
+        uint32_t incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wsum[wv] = incl;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t t = threadIdx.x >= (unsigned)off ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const uint32_t incl = buf[threadIdx.x];
-        if (i < nblocks) block_sums[i] = carry + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
+        uint32_t before = carry, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t t = wsum[w]; if (w < wv) before += t; all += t; }
+        uint32_t run = before + incl - s;
+#pragma unroll
+        for (int k = 0; k < SCANB_ITEMS; ++k) { if (i0 + k < nblocks) block_sums[i0 + k] = run; run += v[k]; }
+        carry += all;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry;
@@ -381,13 +386,13 @@ hipError_t rtk_shade_flags(const DevSceneView& sc, const rt_ray* rays, const rt_
     hipLaunchKernelGGL(k_shade_flags, dim3(nb), dim3(256), 0, st, sc, rays, hits, pix, n, spawn_children,
                        primary_pass, child_flags, srays, sactive, hit_ids, hit_any,
                        reinterpret_cast<unsigned long long*>(block_pairs), code, seed, light_radius);
-    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, block_pairs, (int64_t)nb, counters);
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, block_pairs, (int64_t)nb, counters);
     return hipGetLastError();
 }
 
 hipError_t rtk_reduce_pairs(const unsigned int* block_pairs, int64_t nblocks, unsigned long long* counters, hipStream_t st) {
     if (nblocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, block_pairs, nblocks, counters);
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, block_pairs, nblocks, counters);
     return hipGetLastError();
 }
 
@@ -413,7 +418,7 @@ hipError_t rtk_scan_flags(const uint8_t* flags, int64_t n, uint32_t* block_sums,
     if (n <= 0) return hipSuccess;
     const int64_t nb = rtk_scan_blocks_needed(n);
     hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, n, block_sums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, nb, d_total);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, d_total);
     return hipGetLastError();
 }
 
@@ -425,12 +430,12 @@ hipError_t rtk_compact_children(const DevSceneView& sc, const rt_ray* rays, cons
     if (nflags <= 0) return hipSuccess;
     const int64_t nb = rtk_scan_blocks_needed(nflags);
     hipLaunchKernelGGL(k_scan_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, nflags, block_sums);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, block_sums, nb, d_total);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, d_total);
     // block_sums: [nb] offsets, then (256-byte aligned) [nb][2] per-block child counts by kind
     unsigned int* kind_pairs = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(block_sums) + (((size_t)nb * 4 + 16 + 255) & ~(size_t)255));
     hipLaunchKernelGGL(k_spawn, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, sc, rays, hits, pix, weight, nr_in, flags,
                        nflags, block_sums, orays, opix, oweight, onr, kind_pairs, code, ocode, seed, glossy, ooct, osrc);
-    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(1024), 0, st, kind_pairs, nb, counters + 3);      // [3] reflect, [4] refract children
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, kind_pairs, nb, counters + 3);      // [3] reflect, [4] refract children
     return hipGetLastError();
 }
 
@@ -447,7 +452,7 @@ hipError_t rtk_octant_order(const uint8_t* d_oct, int64_t n, void* d_work, const
     int32_t* order = (int32_t*)d_work;
     uint32_t* hist = (uint32_t*)((char*)d_work + (((size_t)n * 4 + 255) & ~(size_t)255));
     hipLaunchKernelGGL(k_oct_count, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, d_oct, n, nb, hist);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, hist, 8 * nb, hist + 8 * nb);      // octant-major: a stable partition
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, hist, 8 * nb, hist + 8 * nb);      // octant-major: a stable partition
     hipLaunchKernelGGL(k_oct_scatter, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, d_oct, n, nb, hist, order);
     *order_out = order;
     return hipGetLastError();

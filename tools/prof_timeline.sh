@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 tag=${1:-a}; out=gpurun_out/tl_$tag; rm -rf "$out"; mkdir -p "$out"
 timeout -s KILL 240 rocprofv3 --kernel-trace --output-format csv -d "$out" -o r -- python3 tools/exp_drt.py 2 ${2:-1} > "$out/stdout.txt" 2> "$out/stderr.txt"
 rc=$?; tail -n 1 "$out/stdout.txt" | cut -c1-150; if [ $rc -ne 0 ]; then tail -n 5 "$out/stderr.txt"; exit $rc; fi
-python3 - "$out" "$tag" <<'PY'
+python3 - "$out" "$tag" "${3:-100}" <<'PY'
 import csv, glob, sys
 out, tag = sys.argv[1], sys.argv[2]
 rows = []
@@ -22,7 +22,7 @@ qs = {}
 with open(f"gpurun_out/timeline_{tag}.txt", "w") as fo:
     fo.write("# start_ms end_ms duration_ms queue kernel\n")
     for s, e, q, k in rows[a:b]:
-        if e - s < 100000: continue
+        if e - s < int(sys.argv[3]) * 1000: continue
         qn = qs.setdefault(q, "q%d" % (len(qs) + 1))
         fo.write(f"{(s - t0) / 1e6:8.3f} {(e - t0) / 1e6:8.3f} {(e - s) / 1e6:7.3f} {qn} {k[:64]}\n")
 print(open(f"gpurun_out/timeline_{tag}.txt").read())
