@@ -11,7 +11,8 @@ import numpy as np
 from . import abi
 
 
-def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, device="cpu", stats=None, keep_on_device=False):
+def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, device="cpu", stats=None, keep_on_device=False,
+                    exchange_always=False):
     """The `while (stored < max)` emission loops of final.cpp:1057 / :1090, sharded.
 
     emit_fn(first, count) -> uint8 tensor [n, 40] on `device`: the photons stored by emission indices
@@ -21,6 +22,7 @@ def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, dev
     order until `target` photons are there; the first `target` are kept (AddPhoton's capacity test,
     photon.cpp:837).  Returns (numpy photon_dtype[target], emission indices consumed); with keep_on_device the first element
     is a uint8 tensor [target, 40] on `device` instead (the photons never visit the host: rt_photonmap_build_dev takes them).
+    exchange_always: run the collectives with one rank too (tests/dist_rccl_worker.py: the RCCL calls on the one-GPU box).
     """
     import torch
     batch = int(batch or max(4096, -(-target // (4 * world))))
@@ -29,7 +31,7 @@ def emit_photon_map(emit_fn, target, rank=0, world=1, batch=None, dist=None, dev
         first = (rnd * world + rank) * batch
         mine = emit_fn(first, batch)
         assert mine.dtype == torch.uint8 and mine.dim() == 2 and mine.shape[1] == 40
-        if world > 1:
+        if world > 1 or exchange_always:
             cnt = torch.tensor([mine.shape[0]], dtype=torch.int64, device=device)
             counts = [torch.zeros_like(cnt) for _ in range(world)]
             dist.all_gather(counts, cnt)
@@ -76,14 +78,14 @@ def gpu_emitter(scene, e, torch, stream=None):
     return emit
 
 
-def share_from_rank0(make_fn, rank, world, dist, device, torch, src=0):
+def share_from_rank0(make_fn, rank, world, dist, device, torch, src=0, exchange_always=False):
     """One rank builds, everybody holds: rank `src` calls make_fn() -> (uint8 tensor on `device`, list of int64 header
     words); the header and then the payload are broadcast (RCCL over xGMI on the GPUs, gloo in the CPU tests).
     Returns (payload tensor, header list) on every rank.  Used for the balanced photon map: the balance
     (photon.cpp:133-254) is a serial-ish host job of seconds to tens of seconds, so ONE rank per node runs it and the
     others receive the result instead of every rank repeating it on the same host's cores."""
     payload, header = make_fn() if rank == src else (None, None)
-    if world == 1:
+    if world == 1 and not exchange_always:
         return payload, header
     nh = torch.tensor([len(header) if rank == src else 0], dtype=torch.int64, device=device)
     dist.broadcast(nh, src)

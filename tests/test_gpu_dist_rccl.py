@@ -1,0 +1,29 @@
+"""The N > 1 path's collectives over RCCL on the GPU box.  No multi-GPU node is available to this build, so the `nccl` branch
+of raytracer_amd/dist.py and bench.py had never executed anywhere (only its gloo twin, tests/test_dist_gloo.py); this runs
+it with as many ranks as the box has GPUs -- one -- through the launcher the driver uses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_takes_the_exchange_calls_of_the_multi_gpu_path():
+    import torch
+    world = 1                           # one rank per GPU; the box has one (never more ranks than GPUs over RCCL)
+    assert torch.cuda.device_count() >= 1
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "tests", "dist_rccl_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["world"] == world and j["backend"] == "nccl"
+    assert j["all_ok"] and j["gather_ok"] and j["max_float"] == 1.5 + (world - 1) and j["sum_float"] == 2.0 * world
+    for which, target in (("0", 5000), ("1", 300)):
+        m = j["maps"][which]
+        assert m["n"] == target and m["equals_single_process"] and m["broadcast_ok"] and m["allgather_bytes"] > 0, m
