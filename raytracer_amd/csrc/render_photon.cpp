@@ -79,8 +79,14 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
     std::vector<int32_t> tiles;
     rank_microtiles(*cam, *p, tiles);
     const int64_t ntiles = (int64_t)tiles.size();
-    // chunk: about 2^18 samples (so <= 13 M gather rays and 105 MB of occlusion bytes at the reference's settings)
-    const int64_t chunk_tiles = std::max<int64_t>(1, ((int64_t)1 << 18) / (64 * ntap));
+    // chunk: about 2^21 samples -- a 1080p frame whole (105 M gather rays, 22 GB of queues and 0.8 GB of occlusion bytes at the
+    // reference's settings; the memory is taken for the frames that need it, a small frame is one small chunk).  The radiance
+    // estimate is why: a call sorts ITS queries along the Morton curve, so the more queries a call holds the closer the 64 of
+    // a wave lie and the more of their walks the caches share -- BASELINE configuration 4 at full size, per frame:
+    // 2^17 3 561 ms, 2^18 3 187 (the default until round 3), 2^19 2 883, 2^20 2 630, 2^21 2 533, 2^22 the same (one chunk).
+    // RT_PM_CHUNK_LOG2 = 12 .. 22 overrides (2^18: 2.7 GB of queues).
+    static const int chunk_log2 = [] { const char* e = getenv("RT_PM_CHUNK_LOG2"); const int v = e ? atoi(e) : 21; return v < 12 ? 12 : (v > 22 ? 22 : v); }();
+    const int64_t chunk_tiles = std::max<int64_t>(1, ((int64_t)1 << chunk_log2) / (64 * ntap));
     const int64_t T = std::min(ntiles, chunk_tiles);
     const int64_t nps = T * 64, nsmp = nps * ntap;
 
