@@ -71,6 +71,23 @@ for c in range(cases):
     abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_RENDER_OVERLAP, 1))
     two, ids2, st2 = g.render(cam, p, want_ids=True)
     rad, _ = g.render_radiance(cam, p)
+    # walks from the origin's leaf (the default) against walks from the root (RT_LANE_ORIGIN=0), with every secondary ray in
+    # the per-lane kernels (path kernel from depth 1, then passes per lane + path kernel from 2): the same bytes and counts
+    os.environ["RT_LANE_ORIGIN"] = "0"
+    g0 = host.Scene(sd)
+    del os.environ["RT_LANE_ORIGIN"]
+    origin_same = True
+    for pd, ld in ((1, 1), (2, 1)):
+        res_o = []
+        for sc in (g, g0):
+            abi.check(sc.L.rt_scene_set_option(sc.h, abi.RT_OPT_PATH_DEPTH, pd)); abi.check(sc.L.rt_scene_set_option(sc.h, abi.RT_OPT_LANE_DEPTH, ld))
+            fo, io, so = sc.render(cam, p, want_ids=True)
+            ro, _ = sc.render_radiance(cam, p)
+            res_o.append((fo, io, ro, (so.rays_primary, so.rays_reflect, so.rays_refract, so.rays_shadow)))
+        eqr = (res_o[0][2] == res_o[1][2]) | (np.isnan(res_o[0][2]) & np.isnan(res_o[1][2]))
+        origin_same = origin_same and bool(np.array_equal(res_o[0][0], res_o[1][0]) and np.array_equal(res_o[0][1], res_o[1][1]) and eqr.all() and res_o[0][3] == res_o[1][3])
+    g0.close()
+    abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_PATH_DEPTH, 3)); abi.check(g.L.rt_scene_set_option(g.h, abi.RT_OPT_LANE_DEPTH, 2))
     # Triangle::GetNormal re-normalises the stored normal in place on every call (hw4.cpp:135): the reference's frame depends
     # on how often each triangle has been hit before.  The device uses the fixed point, so the oracle renders the
     # frame twice more: where the re-normalisation does not settle (it can alternate between two neighbours), the reference's
@@ -103,7 +120,7 @@ for c in range(cases):
     oprev = oprev.reshape(res[1], res[0], 3)
     self_off = int((~(np.abs(oprev - orad) <= tol) & ~(np.isnan(oprev) & np.isnan(orad))).any(-1).sum())
     rad_ok = bool(off.sum() <= max(1, 0.005 * npx, 3 * self_off) and (d > 1).sum() <= max(1, 0.005 * npx, 3 * self_off))
-    ok = same and ids_ok and counts_ok and rad_ok
+    ok = same and ids_ok and counts_ok and rad_ok and origin_same
     if only >= 0:
         prev = orad
         for rep in range(3):
@@ -123,7 +140,7 @@ for c in range(cases):
         for y, x in list(zip(ys, xs))[:8]:
             print("   px", x, y, "gpu", rad[y, x], "oracle", orad[y, x], "id", ids2.reshape(res[1], res[0])[y, x])
         for md in (1, 2, 3, 5, 8):
-            pm = host.default_params("hw4", max_depth=md, **kw)
+            pm = host.default_params("hw4", **dict(kw, max_depth=md))
             g.set_traversal("bvh")
             _, _, sm = g.render(cam, pm, want_ids=True)
             o.reset()
@@ -136,7 +153,7 @@ for c in range(cases):
     bad += 0 if ok else 1
     print(f"case {c}: {sd.prims.shape[0]} prims {res[0]}x{res[1]} {kw} passes {st2.passes} rays {st2.rays_primary}/{st2.rays_reflect}/"
           f"{st2.rays_refract}/{st2.rays_shadow} streams={'same' if same else 'DIFFER'} ids={'ok' if ids_ok else 'DIFFER'} "
-          f"counts={'ok' if counts_ok else 'DIFFER'} radiance={'ok' if rad_ok else 'DIFFER'} ({int(off.sum())} px off, {int((d > 1).sum())} px > 1 LSB; the oracle against itself: {self_off} px, {self_hits} hits)",
+          f"counts={'ok' if counts_ok else 'DIFFER'} origin-walks={'same' if origin_same else 'DIFFER'} radiance={'ok' if rad_ok else 'DIFFER'} ({int(off.sum())} px off, {int((d > 1).sum())} px > 1 LSB; the oracle against itself: {self_off} px, {self_hits} hits)",
           flush=True)
     g.close(); o.close()
 print(f"{cases} cases, {bad} mismatches")

@@ -1,6 +1,4 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-for v in "RT_PM_CHUNK_LOG2=21" "RT_PM_CHUNK_LOG2=22"; do
-  echo "== $v"
-  env $v timeout -k 10 300 python -u tools/exp_pframe.py full 2>/dev/null | tail -1 | cut -c1-330 || exit $?
-done
+FUZZ_ONLY=0 timeout -k 10 300 python -u tests/fuzz_render.py 100 7 2>&1 | tail -25
+FUZZ_ONLY=30 timeout -k 10 300 python -u tests/fuzz_render.py 100 7 2>&1 | grep -E "mode|oracle frame|case 30" | tail -12
