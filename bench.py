@@ -969,15 +969,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = world if world > 1 else 1
+    # RT_BENCH_FORCE_MULTI=1 (tests/test_gpu_dist_rccl.py): the N > 1 code path -- process group, tiles, packed gather, all-reduces,
+    # the strong-scaling lines -- with however many ranks there are, ONE included: the only way to run it over RCCL on a one-GPU box
+    multi = world > 1 or os.environ.get("RT_BENCH_FORCE_MULTI") == "1"
     dry = args.dry_run
-    rehearse = n > 1 and args.backend == "gloo" and not dry
+    rehearse = multi and args.backend == "gloo" and not dry
     only = [x for x in args.only_secondary.split(",") if x]
     full_size = ("photon_frame_full", "stress_mesh_10m", "stress_knn_200m")
     want = lambda name: (not args.no_knn) and ((name in only) if only else not (args.no_full_size and name in full_size))
 
     # ---- CPU legs that fork (reference binaries, process pool): before anything touches the GPU ----------------------
     cpu = {}
-    if rank == 0 and n == 1 and not dry and not args.no_cpu_baseline:
+    if rank == 0 and (not multi) and not dry and not args.no_cpu_baseline:
         w, h = (int(x) for x in args.cpu_sample.split("x"))
         t0 = time.perf_counter()
         if want("monkey_4k"):
@@ -1007,17 +1010,17 @@ def main():
     dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
     if not dry:
         torch.cuda.set_device(dev)
-    if n > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if (dry or rehearse) else "nccl")
-    coll = Coll(dist, torch, "gloo" if (dry or rehearse) else "nccl") if n > 1 else None
+    coll = Coll(dist, torch, "gloo" if (dry or rehearse) else "nccl") if multi else None
 
     # Every rank of an N > 1 run sits in collectives from here on; if one of them dies or stalls the others would wait for
     # ever.  After RT_BENCH_WATCHDOG_S seconds (default 360) without the run finishing, every rank gives up: rank 0 prints the
     # line as it stands, marked, and the process ends with a NON-ZERO status -- a stalled run must never read as a success.
     out = None
     watchdog = None
-    if n > 1:
+    if multi:
         import threading
 
         def give_up():
@@ -1041,13 +1044,13 @@ def main():
         sd = synth.mesh_scene(1000, 500, reflect=0.3)
         resx, resy = frame_for(n)
     npix = resx * resy
-    packed = n > 1                      # a rank's tiles leave the kernel as one contiguous buffer (rt_params.packed_output)
+    packed = multi                      # a rank's tiles leave the kernel as one contiguous buffer (rt_params.packed_output)
     cam = host.camera_for(sd, (resx, resy))
     scene_s = None
     if not dry:
         gs = host.Scene(sd, device=local_rank)
         scene_s = time.perf_counter() - t0
-        params = host.default_params("hw4", spp=HEAD_SPP, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n,
+        params = host.default_params("hw4", spp=HEAD_SPP, tile_size=TILE if multi else 0, tile_rank=rank, tile_nranks=n,
                                      packed_output=1 if packed else 0, **DRT_KW)
         stream = torch.cuda.current_stream()
         sp = C.c_void_p(stream.cuda_stream)
@@ -1058,16 +1061,16 @@ def main():
         my_pix = None
     else:
         my_pix = torch.from_numpy(rank_pixel_index(resx, resy, rank, n)).to(dev)
-        counts = [len(rank_pixel_index(resx, resy, r, n)) for r in range(n)] if n > 1 else [npix]
+        counts = [len(rank_pixel_index(resx, resy, r, n)) for r in range(n)] if multi else [npix]
     maxc = max(counts)
     frame = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
     sendbuf = [torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-    recv = [[torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(n)] for _ in range(2)] if (n > 1 and rank == 0) else None
+    recv = [[torch.zeros((maxc, 3), dtype=torch.uint8, device=dev) for _ in range(n)] for _ in range(2)] if (multi and rank == 0) else None
     final = torch.zeros((npix, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
     if packed:
         all_pix = [torch.from_numpy(l.astype(np.int64)).to(dev) for l in lists] if rank == 0 else None
     else:
-        all_pix = [torch.from_numpy(rank_pixel_index(resx, resy, r, n)).to(dev) for r in range(n)] if (n > 1 and rank == 0) else None
+        all_pix = [torch.from_numpy(rank_pixel_index(resx, resy, r, n)).to(dev) for r in range(n)] if (multi and rank == 0) else None
     st = abi.rt_stats()
     tot = dict(rays=0)
     pending = [None, None]
@@ -1096,7 +1099,7 @@ def main():
                                          None, C.byref(st) if timed == "stats" else None, sp))
             if timed == "stats":
                 tot["rays"] += st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract
-        if n > 1:
+        if multi:
             if pending[b] is not None:                # the buffer pair of two steps ago must have left
                 pending[b].wait()
             if not packed:
@@ -1126,20 +1129,20 @@ def main():
     def sync():
         if not dry:
             torch.cuda.synchronize()
-        if n > 1:
+        if multi:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i, False)
-    if n > 1:
+    if multi:
         drain()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)
-    if n > 1:
+    if multi:
         drain()
     sync()
     dt = time.perf_counter() - t0
@@ -1149,11 +1152,11 @@ def main():
         nstat = max(1, min(args.steps, 2))
         for i in range(nstat):
             step(i, "stats")
-        if n > 1:
+        if multi:
             drain()
         sync()
         tot["rays"] = tot["rays"] / nstat * args.steps
-    if n > 1:
+    if multi:
         cdev = "cpu" if (dry or rehearse) else dev
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1166,7 +1169,7 @@ def main():
 
     if dry:
         if rank == 0:
-            if n > 1:
+            if multi:
                 ok = True
                 for r in range(n):
                     pix = all_pix[r][all_pix[r] >= 0]
@@ -1177,7 +1180,7 @@ def main():
             else:
                 ok = True
             out = {"dry_run": True, "n_gpus": n, "frame": [resx, resy], "assembled_ok": ok, "pixels_per_rank": counts}
-        if n > 1:
+        if multi:
             stall = os.environ.get("RT_BENCH_TEST_STALL_RANK")       # tests only: this rank never reaches the last barrier
             if stall is not None and int(stall) == rank:
                 time.sleep(3600)
@@ -1200,7 +1203,7 @@ def main():
                           "parallelism": f"tiles{TILE}x{TILE} round-robin over {n} GPU(s), scene replicated, gather to rank 0"}}
         if rehearse:
             out["config"]["rehearsal"] = "gloo backend, every rank on GPU 0, collectives staged through the host: NOT a measurement"
-        if n > 1:
+        if multi:
             # the frame rank 0 assembled from the ranks' last gather against the same frame rendered whole on rank 0
             pw = host.default_params("hw4", spp=HEAD_SPP, **DRT_KW)
             abi.check(gs.L.rt_render_dev(gs.h, C.byref(cam), C.byref(pw), frame.data_ptr(), None, None, sp))
@@ -1212,7 +1215,7 @@ def main():
         # roofline of the dominant kernel (counters of the committed profile, time live), CPU leg, parity sample: on this
         # rank's share of the frame (N = 1: the whole frame)
         try:
-            pa = host.default_params("hw4", spp=HEAD_SPP, tile_size=TILE if n > 1 else 0, tile_rank=rank, tile_nranks=n, **DRT_KW)
+            pa = host.default_params("hw4", spp=HEAD_SPP, tile_size=TILE if multi else 0, tile_rank=rank, tile_nranks=n, **DRT_KW)
             an = drt_analysis(torch, gs, sd, cam, pa, sp, with_cpu=not args.no_cpu_baseline)
             out["roofline"] = an["roofline"]
             if an["cpu_baseline"]:
@@ -1225,7 +1228,7 @@ def main():
         except Exception as e:
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
             failed.append("headline: instrumented frames")
-        if n == 1 and not args.no_knn:
+        if (not multi) and not args.no_knn:
             sec = {}
             for name, fn in (("monkey_4k", lambda: monkey_secondary(torch, local_rank, cpu=cpu.get("monkey_4k"))),
                              ("mesh_1m", lambda: mesh_secondary(torch, local_rank, cpu=cpu.get("mesh_1m"))),
@@ -1248,7 +1251,7 @@ def main():
                 if line_failed(sec[name]):
                     failed.append(name)
             out["secondary"] = sec
-    if n > 1 and not args.no_knn:
+    if multi and not args.no_knn:
         sec = {}
         # the metric's second half at N GPUs: every rank answers its own share of the radiance lookups (the queries
         # follow their pixels, the photon map is replicated, no exchange: SURVEY 8e), weak scaling like the frame
@@ -1284,7 +1287,7 @@ def main():
         if rank == 0:
             out["secondary"] = sec
             failed += [k for k, v in sec.items() if line_failed(v)]
-    if n > 1:
+    if multi:
         dist.barrier()
         watchdog.cancel()
         dist.destroy_process_group()
@@ -1294,7 +1297,7 @@ def main():
             out["failed_lines"] = failed
             rc = EXIT_LINE_FAILED
         print(dumps(out), flush=True)
-    if n > 1 and not dry:
+    if multi and not dry:
         # every rank leaves with the same status
         pass
     return rc

@@ -27,3 +27,23 @@ def test_rccl_takes_the_exchange_calls_of_the_multi_gpu_path():
     for which, target in (("0", 5000), ("1", 300)):
         m = j["maps"][which]
         assert m["n"] == target and m["equals_single_process"] and m["broadcast_ok"] and m["allgather_bytes"] > 0, m
+
+
+def test_bench_multi_rank_path_over_rccl_with_the_ranks_the_box_has():
+    """bench.py's N > 1 code path as the driver launches it (torch.distributed.run, backend nccl), forced on with one rank
+    (RT_BENCH_FORCE_MULTI=1): process group, tiles + packed output, the asynchronous gather to rank 0 and the frame's
+    re-assembly, the all-reduces over the ranks' times and ray counts, and the lines that only exist for N > 1 (kNN
+    aggregate, drt_1m_strong, emission_sharded).  The assembled frame must equal the frame rendered whole, no line may
+    fail, exit status 0."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", RT_BENCH_FORCE_MULTI="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29572", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and "failed_lines" not in j
+    assert j["config"]["assembled_frame_equals_one_gpu_frame"] is True
+    sec = j["secondary"]
+    assert set(sec) == {"knn", "drt_1m_strong", "emission_sharded"}
+    assert sec["drt_1m_strong"]["config"]["assembled_frame_equals_one_gpu_frame"] is True
+    assert sec["emission_sharded"]["config"]["heap_equals_one_rank_heap"] and sec["emission_sharded"]["config"]["every_rank_answers_alike"]
