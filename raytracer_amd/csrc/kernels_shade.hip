@@ -224,8 +224,10 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         uint64_t seed, float glossy, uint8_t* __restrict__ ooct, int32_t* __restrict__ osrc) {
     __shared__ uint32_t wsum[SCAN_BLOCK / 64];
     __shared__ unsigned int kinds[2];
+    __shared__ uint16_t list[SCAN_TILE];                                 // the tile's flagged slots (tile-local index), in slot order
     if (threadIdx.x < 2) kinds[threadIdx.x] = 0;
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    const int64_t tile0 = (int64_t)blockIdx.x * SCAN_TILE;
+    const int64_t base = tile0 + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint8_t f[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
@@ -236,14 +238,24 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
     for (int off = 1; off < 64; off <<= 1) { uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
     if (lane == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-    uint32_t pos = block_offsets[blockIdx.x] + woff + incl - s;
-    int nrefl = 0, nrefr = 0;
+    uint32_t woff = 0, tile_total = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (!f[k]) continue;
-        const int64_t slot = base + k, i = slot >> 1;
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) { const uint32_t t = wsum[w]; if (w < (int)(threadIdx.x >> 6)) woff += t; tile_total += t; }
+    // Children are made from the COMPACTED list, one per lane: about a fifth of the slots of config 3's first pass carry a child,
+    // and made where they stand -- eight slots per lane, one after the other -- every wave ran the child's arithmetic (glossy lobe
+    // in double, hit context, eight stores) eight times with a fifth of its lanes.  Same children at the same positions: entry j
+    // of the tile's list goes to block_offsets[tile] + j, which is where its slot's rank put it before.
+    {
+        uint32_t lp = woff + incl - s;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) if (f[k]) list[lp++] = (uint16_t)(threadIdx.x * SCAN_ITEMS + k);
+    }
+    __syncthreads();
+    const uint32_t pos0 = block_offsets[blockIdx.x];
+    int nrefl = 0, nrefr = 0;
+    for (uint32_t j = threadIdx.x; j < tile_total; j += SCAN_BLOCK) {
+        const int64_t slot = tile0 + (int64_t)list[j], i = slot >> 1;
+        const uint32_t pos = pos0 + j;
         HitCtx c;
         load_hit(sc, rays, hits, i, c);
         const DevMaterial m = sc.materials[c.mat];
@@ -263,7 +275,6 @@ k_spawn(DevSceneView sc, const rt_ray* __restrict__ rays, const rt_hit* __restri
         if (ooct) ooct[pos] = (uint8_t)((o[3] < 0.f ? 1u : 0u) | (o[4] < 0.f ? 2u : 0u) | (o[5] < 0.f ? 4u : 0u));   // k_ray_keys' octant
         if (ocode) ocode[pos] = child_code(code[i], (unsigned)(slot & 1));
         if (osrc) osrc[pos] = c.prim;                                       // the triangle the child starts on (RaySrc)
-        ++pos;
     }
     if (nrefl) atomicAdd(&kinds[0], (unsigned)nrefl);
     if (nrefr) atomicAdd(&kinds[1], (unsigned)nrefr);
