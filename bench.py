@@ -156,15 +156,23 @@ def counters(workload, kernel):
     return None, w["prov"]
 
 
-def make_roofline(workload, kernel, avg_ms, units_per_launch, alg_bytes, wave_bytes=None, **detail):
+def make_roofline(workload, kernel, avg_ms, units_per_launch, alg_bytes, wave_bytes=None, counter_scale=1.0, **detail):
     """The dominant kernel against the three limiters the counters can speak for.
       hbm      useful HBM bytes / time / 8 TB/s, useful = min(algorithmic bytes, PMC traffic): what the algorithm needs
                out of what was moved (traffic above the algorithmic bytes is waste, algorithmic bytes above the traffic
                were served by the scalar cache / L2 and never were HBM's to deliver)
       valu     vector wave-instructions / time / (1024 SIMDs x 2.4 GHz / 2 cycles)
       scalar   SALU + SMEM + branch instructions / time / (256 CUs x 2.4 GHz)
-    `bound` names the largest, achieved / peak / unit / frac are its numbers (<= 1 by construction)."""
+    `bound` names the largest, achieved / peak / unit / frac are its numbers (<= 1 by construction).
+    counter_scale: the committed counters are means over EVERY launch of the kernel in the profiled run; where that run also
+    holds launches that are not the workload's (the photon frame's 10x10 parity sample: as many launches, next to no work)
+    the caller gives the ratio all launches / the workload's launches, and the per-launch counts are scaled by it."""
     c, src = counters(workload, kernel)
+    if c and counter_scale != 1.0:
+        c = dict(c)
+        for key in ("hbm_bytes_per_launch", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+            if c.get(key):
+                c[key] = c[key] * counter_scale
     t = max(avg_ms, 1e-9) * 1e-3
     traffic = c.get("hbm_bytes_per_launch") if c else None
     useful = min(alg_bytes, traffic) if traffic else None
@@ -707,8 +715,11 @@ def photon_frame_secondary(torch, local_rank, n_global=1_000_000, n_caustic=100_
     visits = float(ks[0] + ks[12]) / max(1, st.knn_lookups)
     bytes_per = 24 + 16 * visits + 12 * float(p.knn_k) + 12
     launches = max(1, st.knn_launches)
+    # (the profiled run = this function: one instrumented frame, the timed ones, the counted one -- and the 10x10 parity sample,
+    # whose radiance-estimate launches are as many and carry next to nothing)
+    full_frames = nframes + 2
     rf = make_roofline(tag, "k_irr_main", st.knn_ms / launches, st.knn_lookups / launches, bytes_per * st.knn_lookups / launches,
-                       visits_per_lookup=visits, bytes_per_lookup=bytes_per, launches_per_frame=launches,
+                       counter_scale=(full_frames + 1) / full_frames, visits_per_lookup=visits, bytes_per_lookup=bytes_per, launches_per_frame=launches,
                        ms_per_frame_in_the_estimate=st.knn_ms,
                        time_is="all radiance-estimate calls of the frame (query sort + k_irr_main + strict redo), HIP events",
                        waves=int(ks[6]), strict_redo_queries=int(ks[5]), waves_gave_up=int(ks[11]),
