@@ -464,6 +464,24 @@ __device__ __forceinline__ void consider_uniform(float (&hd)[REDO_S], int (&hi)[
     wr_i(hi, parent, index, lane); wr_f(hd, parent, dist2, lane);
     r2 = rd_f(hd, 1);
 }
+// the key of slot sidx's turn in the reference's visiting order for the query (qx, qy, qz): per ancestor two bits, 0 = the
+// query's near side, 1 = the far side; 2 at the slot's own depth = its own turn, after both subtrees (photon.cpp:58-78)
+__device__ __forceinline__ unsigned long long redo_visit_key(const DevPhoton* __restrict__ ph, unsigned sidx, float qx, float qy, float qz) {
+    const int d = 31 - __builtin_clz(sidx);
+    unsigned long long key = 2ull << (62 - 2 * d);
+    for (int j = 0; j < d; ++j) {
+        const unsigned a = sidx >> (d - j);                         // the ancestor at depth j
+        const float4 rec = *reinterpret_cast<const float4*>(ph + a);
+        const int plane = __float_as_int(rec.w) & 3;
+        const float pp = plane == 0 ? rec.x : (plane == 1 ? rec.y : rec.z);
+        const float qp = plane == 0 ? qx : (plane == 1 ? qy : qz);
+        const float dist1 = qp - pp;                                // photon.cpp:61
+        const unsigned near_right = dist1 > 0.0f ? 1u : 0u;
+        const unsigned side = (sidx >> (d - j - 1)) & 1u;
+        key |= (unsigned long long)(side == near_right ? 0u : 1u) << (62 - 2 * j);
+    }
+    return key;
+}
 }  // namespace
 
 // WALK 1 (default): LocatePhoton's recursion on an explicit stack, and whole six-level windows of the heap skipped at once.
@@ -482,12 +500,34 @@ __device__ __forceinline__ void consider_uniform(float (&hd)[REDO_S], int (&hi)[
 // reference's walk is hundreds of thousands of nodes long (200 ms for ONE query, the whole of config 4's strict-redo cost);
 // it becomes a few thousand windows.  A window with a candidate is walked node by node from the stack.
 // WALK 0: the stackless walk of rounds 1-2 (RT_KNN_REDO_WALK=0).
+// WALK 2 (default since round 3's third session): WALK 1 -- and, for a walk that is still going REDO_SWITCH stack items after
+// the reference's heap was built (a query of ~1 000 accepted photons in a spatially ordered heap is done by then), NO walk of
+// the reference's heap for the rest.  Once its heap exists the reference accepts a photon only if its dist2 is below the
+// radius of that moment, which never grows: every photon that can still be accepted lies within the radius R of NOW.  Those are found in the SECOND heap (spatially ordered,
+// a box per sub-heap: a wave-wide frontier walk, ~20 rounds), each gets the key of its turn in the reference's visiting
+// order -- per ancestor in the reference's heap one digit, 0 = the query's near side, 1 = the far side, and 2 for the node's
+// own turn after both subtrees (photon.cpp:58-78) -- the keys are sorted, and the reference's `consider` runs over them in
+// that order: the same photons are accepted in the same order into the same arrays, so np.index, np.dist2 and the sum are
+// the reference's bit for bit.  (A far subtree the reference does not enter holds only photons with dist2 >= dist1^2 >= the
+// radius of that moment: `consider` rejects them here as the reference would have, had it looked.)  What this replaces is
+// the walk, not the list: in a heap without spatial order (the caustic map's coplanar photons, every third level splits on
+// y with dist1 = 0) one query's walk took up to 175 ms; the keys cost ~25 fetches per candidate, all independent.  Run from
+// the start it loses to WALK 1 on ordinary queries (3.7 against 1.0 ms per query: the radius is still wide when the heap is
+// built), hence the switch.  More than REDO_CAND candidates or a frontier wider than REDO_FRONT: WALK 1 simply goes on.
+#define REDO_CAND 1024
+#define REDO_FRONT 1024
+#define REDO_SWITCH 10000
 template <int WALK>
 __global__ void __launch_bounds__(64)
 k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
                   const float* __restrict__ nrm3, int k, float maxDist, float* __restrict__ out_rgb,
-                  const float* __restrict__ tables, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist) {
+                  const float* __restrict__ tables, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist,
+                  unsigned redo_switch) {
     __shared__ float4 win[64];
+    __shared__ unsigned long long c_key[WALK == 2 ? REDO_CAND : 1];  // WALK 2: candidates: visiting-order key,
+    __shared__ unsigned c_slot[WALK == 2 ? REDO_CAND : 1];          // ... slot in the reference's heap
+    __shared__ unsigned fq[WALK == 2 ? 2 * REDO_FRONT : 1];         // ... the frontier of the second heap's walk, two buffers
+    __shared__ unsigned cnts[4];                                    // ... candidates, next frontier
     __shared__ unsigned stk_i[WALK ? 512 : 1];                      // WALK 1: pending items: node | kind << 30 (0 subtree, 2 the node itself)
     __shared__ float stk_m[WALK ? 512 : 1];                         // ... and the largest far-step dist1^2 on the way to it (-1: none)
     __shared__ unsigned ord_i[WALK ? 64 : 1];                       // a window's exits by visiting order
@@ -504,11 +544,114 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
         float hd[REDO_S] = {0.f, 0.f}; int hi[REDO_S] = {0, 0};
         float r2 = maxDist * maxDist;                               // np.dist2[0], photon.cpp:405
         int found = 0, got_heap = 0;
-        if (WALK == 1) {
+        if (WALK >= 1) {
+            bool tried = false;                                     // WALK 2: the candidates were tried once (too many: the walk goes on)
+            unsigned last_idx = 0;                                  // the photon `consider` saw last
             int sp = 0;
             if (n >= 1) { if (lane == 0) { stk_i[0] = 1u; stk_m[0] = -1.0f; } sp = 1; }
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+            unsigned pops = 0;
             while (sp > 0) {
+                // WALK 2: a walk that is still going REDO_SWITCH items after the heap was built is in a heap without spatial order:
+                // what is left of it is done by keys (everything up to last_idx's turn is behind the walk; what it skipped since
+                // cannot be accepted any more and is rejected again)
+                if (WALK == 2 && got_heap && !tried && ++pops > redo_switch) {
+                    // every photon that can still be accepted, in the reference's order; ok = false: too many, the walk goes on
+                    tried = true;
+                    bool ok = false;
+                    {
+                const DevPhotonPos* __restrict__ pp2 = ph + 2 * (n + 1);
+                const DevPhotonPow* __restrict__ pq2 = reinterpret_cast<const DevPhotonPow*>(pp2 + (n + 2));
+                const float4* __restrict__ bx = reinterpret_cast<const float4*>(pq2 + (n + 1));
+                const unsigned un = (unsigned)n, nb = (unsigned)(n / 2);
+                const float R = r2;
+                if (lane == 0) { cnts[0] = 0u; cnts[1] = 0u; fq[0] = 1u; }
+                __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                unsigned ncur = 1u, cur = 0u;
+                bool over = false;
+                while (ncur > 0u && !over) {
+                    for (unsigned base = 0; base < ncur; base += 64u) {
+                        const unsigned node = base + lane < ncur ? fq[cur * REDO_FRONT + base + lane] : 0u;
+                        if (node != 0u) {
+                            const float4 rec = *reinterpret_cast<const float4*>(pp2 + node);
+                            float d1 = rec.x - qx; float dist2 = d1 * d1;
+                            d1 = rec.y - qy; dist2 += d1 * d1;
+                            d1 = rec.z - qz; dist2 += d1 * d1;
+                            if (dist2 < R && !((unsigned)__float_as_int(rec.w) & RT_PH_UNREACHABLE)) {
+                                const unsigned at = atomicAdd(&cnts[0], 1u);
+                                if (at < REDO_CAND) c_slot[at] = pq2[node].pad;
+                            }
+                            const unsigned c0 = 2u * node;
+                            for (unsigned c = c0; c <= c0 + 1u && c <= un; ++c) {
+                                bool want = true;
+                                if (c <= nb) {
+                                    const float4 lo = bx[2 * c], hi4 = bx[2 * c + 1];
+                                    const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi4.x), 0.0f);
+                                    const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi4.y), 0.0f);
+                                    const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi4.z), 0.0f);
+                                    float bd = dx * dx; bd += dy * dy; bd += dz * dz;    // <= the dist2 of every photon inside (w_boxdist)
+                                    want = bd < R;
+                                }
+                                if (want) {
+                                    const unsigned at = atomicAdd(&cnts[1], 1u);
+                                    if (at < REDO_FRONT) fq[(cur ^ 1u) * REDO_FRONT + at] = c;
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                    const unsigned nnext = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[1]);
+                    const unsigned ncand_now = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[0]);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) cnts[1] = 0u;
+                    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                    over = nnext > REDO_FRONT || ncand_now > REDO_CAND;
+                    ncur = nnext; cur ^= 1u;
+                }
+                if (!over) {
+                const unsigned nc = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[0]);
+                // keys; what the walk has seen already (everything up to last_idx's turn) gets the largest key and is skipped below
+                const unsigned long long seen = redo_visit_key(ph, last_idx, qx, qy, qz);
+                unsigned np2 = 64u; while (np2 < nc) np2 <<= 1;
+                for (unsigned t = lane; t < np2; t += 64u) {
+                    unsigned long long key = ~0ull;
+                    if (t < nc) { key = redo_visit_key(ph, c_slot[t], qx, qy, qz); if (key <= seen) key = ~0ull; }
+                    c_key[t] = key;
+                }
+                __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                // bitonic sort of (key, slot), ascending
+                for (unsigned kk = 2u; kk <= np2; kk <<= 1) {
+                    for (unsigned jj = kk >> 1; jj > 0u; jj >>= 1) {
+                        for (unsigned t = lane; t < np2; t += 64u) {
+                            const unsigned u = t ^ jj;
+                            if (u > t) {
+                                const unsigned long long a = c_key[t], b = c_key[u];
+                                const bool up = (t & kk) == 0u;
+                                if ((a > b) == up) {
+                                    c_key[t] = b; c_key[u] = a;
+                                    const unsigned sa = c_slot[t]; c_slot[t] = c_slot[u]; c_slot[u] = sa;
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                // the reference's `consider`, photon by photon in its order (dist2 from the reference's own record, photon.cpp:73-77)
+                for (unsigned t = 0; t < nc; ++t) {
+                    const unsigned long long key = c_key[t];
+                    if (key == ~0ull) break;
+                    const unsigned sl = (unsigned)__builtin_amdgcn_readfirstlane((int)c_slot[t]);
+                    const float4 rec = *reinterpret_cast<const float4*>(ph + sl);
+                    float d1 = rec.x - qx; float dist2 = d1 * d1;
+                    d1 = rec.y - qy; dist2 += d1 * d1;
+                    d1 = rec.z - qz; dist2 += d1 * d1;
+                    consider_uniform(hd, hi, lane, k, found, got_heap, r2, (int)sl, rl_f(dist2, 0));
+                }
+                ok = true;
+                }
+                    }
+                    if (ok) break;
+                }
                 --sp;
                 const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)stk_i[sp]);
                 const float m0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(stk_m[sp])));
@@ -519,6 +662,7 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
                     d1 = rec.y - qy; dist2 += d1 * d1;
                     d1 = rec.z - qz; dist2 += d1 * d1;
                     consider_uniform(hd, hi, lane, k, found, got_heap, r2, (int)idx, rl_f(dist2, 0));
+                    last_idx = idx;
                     continue;
                 }
                 if (!(m0 < r2)) continue;                           // (1): nothing below can be accepted any more
@@ -528,6 +672,7 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
                     d1 = rec.y - qy; dist2 += d1 * d1;
                     d1 = rec.z - qz; dist2 += d1 * d1;
                     consider_uniform(hd, hi, lane, k, found, got_heap, r2, (int)idx, rl_f(dist2, 0));
+                    last_idx = idx;
                     continue;
                 }
                 // the window below idx: six levels, or what the heap still has (a node from `uhalf` on does not recurse, one beyond
@@ -734,13 +879,18 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
                 if (e != hipSuccess) return e;
                 rs = redo_st;
             }
-            static const bool old_walk = [] { const char* v = getenv("RT_KNN_REDO_WALK"); return v && atoi(v) == 0; }();
-            if (old_walk || n >= ((int64_t)1 << 30))
+            const int walk_env = [] { const char* v = getenv("RT_KNN_REDO_WALK"); return v ? atoi(v) : 2; }();
+            const unsigned redo_switch = [] { const char* v = getenv("RT_KNN_REDO_SWITCH"); return v ? (unsigned)atoi(v) : (unsigned)REDO_SWITCH; }();
+            const bool old_walk = walk_env == 0;
+            if (!old_walk && walk_env != 1 && n < ((int64_t)1 << 30))
+                hipLaunchKernelGGL(k_photon_knn_redo<2>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
+                                   (const int32_t*)list, (const unsigned*)nlist, redo_switch);
+            else if (old_walk || n >= ((int64_t)1 << 30))
                 hipLaunchKernelGGL(k_photon_knn_redo<0>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
-                                   (const int32_t*)list, (const unsigned*)nlist);
+                                   (const int32_t*)list, (const unsigned*)nlist, redo_switch);
             else
                 hipLaunchKernelGGL(k_photon_knn_redo<1>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
-                                   (const int32_t*)list, (const unsigned*)nlist);
+                                   (const int32_t*)list, (const unsigned*)nlist, redo_switch);
             if (trace) {
                 (void)hipEventRecord(ev[2], st); (void)hipEventSynchronize(ev[2]);
                 unsigned nl = 0; (void)hipMemcpy(&nl, nlist, 4, hipMemcpyDeviceToHost);
