@@ -597,7 +597,7 @@ hipError_t rtk_photon_irr_wave(const DevPhoton* ph, int64_t n, int64_t half, con
     }
     // phase-2 node visits a wave may spend before it gives up (the mean is 1 000 - 2 000 at k = 100): the launch
     // ends when its longest wave does, and the strict kernel spreads the 64 queries over 16 waves.
-    static const unsigned budget_env = getenv("RT_KNN_BUDGET") ? (unsigned)atoi(getenv("RT_KNN_BUDGET")) : 0u;
+    const unsigned budget_env = getenv("RT_KNN_BUDGET") ? (unsigned)atoi(getenv("RT_KNN_BUDGET")) : 0u;      // (read at every call: the tests set it)
     const unsigned budget = budget_env ? budget_env : 16384u;
     // which walk: RT_KNN_WALK=wave|lane (read at every call), else by the photons per query: above 3 the queries'
     // neighbourhoods hardly overlap and the per-lane walk wins (10 M photons under 2.07 M queries: 117 against 104 M

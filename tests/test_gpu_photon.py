@@ -203,6 +203,49 @@ def test_lattice_of_ties_goes_through_the_strict_redo(gscene):
         assert _irr_equal(gscene, rgb, _oracle_irr(heap, qp, qn, k, maxd)), (k, maxd)
 
 
+def test_strict_redo_by_keys_is_the_references_list(monkeypatch):
+    """The strict redo finishes a long walk by KEYS (kernels_photon.hip, WALK 2): the photons that can still be accepted come
+    from the second heap, are sorted by the key of their turn in the reference's visiting order and go through the
+    reference's `consider` in that order.  Here EVERY query is sent to the strict kernel (the wave-shared walk with a budget
+    of one node gives all of them up) and the switch to keys is forced at once, after 37 and after 400 stack items
+    (RT_KNN_REDO_SWITCH): the irradiance must be the stack walk's bits (RT_KNN_REDO_WALK=1) and the oracle's CalcIrradiance
+    bit for bit -- on a map with a coplanar third (the caustic map's shape, where the walk is long), a lattice with
+    duplicates (ties) and queries ON photons."""
+    sd = scene.parse_scene_file(os.path.join(ol.GOLDEN, "final_input.txt"), flavour="final")
+    s = host.Scene(sd)
+    s.set_knn("fast")
+    monkeypatch.setenv("RT_KNN_WALK", "wave"); monkeypatch.setenv("RT_KNN_BUDGET", "1")
+    rng = np.random.default_rng(11)
+    a = _random_map(60000, 5)
+    n1 = 12
+    ax = (np.arange(n1, dtype=np.float32) / np.float32(n1) - np.float32(0.5))
+    pts = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    lat = np.zeros(pts.shape[0] + pts[::3].shape[0], abi.photon_dtype)
+    lat["position"] = np.concatenate([pts, pts[::3]]); lat["power"] = np.float32(1e-5)
+    lat["phi"] = rng.integers(0, 256, lat.size); lat["theta"] = rng.integers(0, 256, lat.size)
+    a = np.concatenate([a, lat])
+    n = a.size - 1
+    heap = s.photonmap_build(abi.RT_PMAP_GLOBAL, a)
+    qp = np.concatenate([rng.uniform(-0.5, 0.5, (500, 3)).astype(np.float32),
+                         a["position"][1 + rng.integers(0, n, 300)],                     # ON photons (lattice points among them)
+                         np.concatenate([rng.uniform(-0.5, 0.5, (200, 1)), np.full((200, 1), -0.5), rng.uniform(-0.5, 0.5, (200, 1))], 1).astype(np.float32)])
+    qn = rng.normal(size=qp.shape).astype(np.float32)
+    try:
+        for k, maxd in ((100, 1.0), (100, 0.1), (30, 0.05), (112, 0.3), (8, 0.02)):
+            want = _oracle_irr(heap, qp, qn, k, maxd)
+            got = {}
+            for walk, switch in (("1", None), ("2", "0"), ("2", "37"), ("2", "400"), ("2", None)):
+                monkeypatch.setenv("RT_KNN_REDO_WALK", walk)
+                if switch is None: monkeypatch.delenv("RT_KNN_REDO_SWITCH", raising=False)
+                else: monkeypatch.setenv("RT_KNN_REDO_SWITCH", switch)
+                got[(walk, switch)] = s.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, k, maxd)
+            for key, rgb in got.items():
+                assert rgb.tobytes() == want.tobytes(), (k, maxd, key, int((rgb.view(np.uint32) != want.view(np.uint32)).any(-1).sum()))
+            assert (want != 0).any(-1).sum() > 300
+    finally:
+        s.close()
+
+
 def test_coherent_queries_share_a_walk(gscene):
     """the wave-shared radiance estimate (RT_KNN_FAST: 64 neighbouring queries per walk, lists of the k smallest dist2 in
     registers) on queries that ARE neighbours -- a dense patch on a wall and a dense patch in free space --
