@@ -516,13 +516,14 @@ __device__ __forceinline__ unsigned long long redo_visit_key(const DevPhoton* __
 // built), hence the switch.  More than REDO_CAND candidates or a frontier wider than REDO_FRONT: WALK 1 simply goes on.
 #define REDO_CAND 1024
 #define REDO_FRONT 1024
-#define REDO_SWITCH 10000
+#define REDO_SWITCH 3000
+#define REDO_GIVEUP 25000
 template <int WALK>
 __global__ void __launch_bounds__(64)
 k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
                   const float* __restrict__ nrm3, int k, float maxDist, float* __restrict__ out_rgb,
                   const float* __restrict__ tables, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist,
-                  unsigned redo_switch) {
+                  unsigned redo_switch, int give_up_after, int32_t* __restrict__ list2, unsigned* __restrict__ nlist2) {
     __shared__ float4 win[64];
     __shared__ unsigned long long c_key[WALK == 2 ? REDO_CAND : 1];  // WALK 2: candidates: visiting-order key,
     __shared__ unsigned c_slot[WALK == 2 ? REDO_CAND : 1];          // ... slot in the reference's heap
@@ -544,6 +545,7 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
         float hd[REDO_S] = {0.f, 0.f}; int hi[REDO_S] = {0, 0};
         float r2 = maxDist * maxDist;                               // np.dist2[0], photon.cpp:405
         int found = 0, got_heap = 0;
+        bool deferred = false;
         if (WALK >= 1) {
             bool tried = false;                                     // WALK 2: the candidates were tried once (too many: the walk goes on)
             unsigned last_idx = 0;                                  // the photon `consider` saw last
@@ -551,107 +553,17 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
             if (n >= 1) { if (lane == 0) { stk_i[0] = 1u; stk_m[0] = -1.0f; } sp = 1; }
             __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
             unsigned pops = 0;
+            bool gave_up = false;
+            for (;;) {                                              // (twice at most: the walk, the finish by keys, and the walk again if that gave up)
+            bool want_keys = false;
             while (sp > 0) {
+                // WALK 1 with a limit: a walk that is still going `give_up_after` items after the heap was built is left to the
+                // launch that follows (WALK 2 over list2), which can finish it by keys
+                if (WALK == 1 && give_up_after >= 0 && got_heap && (int)++pops > give_up_after) { gave_up = true; break; }
                 // WALK 2: a walk that is still going REDO_SWITCH items after the heap was built is in a heap without spatial order:
                 // what is left of it is done by keys (everything up to last_idx's turn is behind the walk; what it skipped since
                 // cannot be accepted any more and is rejected again)
-                if (WALK == 2 && got_heap && !tried && ++pops > redo_switch) {
-                    // every photon that can still be accepted, in the reference's order; ok = false: too many, the walk goes on
-                    tried = true;
-                    bool ok = false;
-                    {
-                const DevPhotonPos* __restrict__ pp2 = ph + 2 * (n + 1);
-                const DevPhotonPow* __restrict__ pq2 = reinterpret_cast<const DevPhotonPow*>(pp2 + (n + 2));
-                const float4* __restrict__ bx = reinterpret_cast<const float4*>(pq2 + (n + 1));
-                const unsigned un = (unsigned)n, nb = (unsigned)(n / 2);
-                const float R = r2;
-                if (lane == 0) { cnts[0] = 0u; cnts[1] = 0u; fq[0] = 1u; }
-                __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-                unsigned ncur = 1u, cur = 0u;
-                bool over = false;
-                while (ncur > 0u && !over) {
-                    for (unsigned base = 0; base < ncur; base += 64u) {
-                        const unsigned node = base + lane < ncur ? fq[cur * REDO_FRONT + base + lane] : 0u;
-                        if (node != 0u) {
-                            const float4 rec = *reinterpret_cast<const float4*>(pp2 + node);
-                            float d1 = rec.x - qx; float dist2 = d1 * d1;
-                            d1 = rec.y - qy; dist2 += d1 * d1;
-                            d1 = rec.z - qz; dist2 += d1 * d1;
-                            if (dist2 < R && !((unsigned)__float_as_int(rec.w) & RT_PH_UNREACHABLE)) {
-                                const unsigned at = atomicAdd(&cnts[0], 1u);
-                                if (at < REDO_CAND) c_slot[at] = pq2[node].pad;
-                            }
-                            const unsigned c0 = 2u * node;
-                            for (unsigned c = c0; c <= c0 + 1u && c <= un; ++c) {
-                                bool want = true;
-                                if (c <= nb) {
-                                    const float4 lo = bx[2 * c], hi4 = bx[2 * c + 1];
-                                    const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi4.x), 0.0f);
-                                    const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi4.y), 0.0f);
-                                    const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi4.z), 0.0f);
-                                    float bd = dx * dx; bd += dy * dy; bd += dz * dz;    // <= the dist2 of every photon inside (w_boxdist)
-                                    want = bd < R;
-                                }
-                                if (want) {
-                                    const unsigned at = atomicAdd(&cnts[1], 1u);
-                                    if (at < REDO_FRONT) fq[(cur ^ 1u) * REDO_FRONT + at] = c;
-                                }
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-                    const unsigned nnext = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[1]);
-                    const unsigned ncand_now = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[0]);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) cnts[1] = 0u;
-                    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-                    over = nnext > REDO_FRONT || ncand_now > REDO_CAND;
-                    ncur = nnext; cur ^= 1u;
-                }
-                if (!over) {
-                const unsigned nc = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[0]);
-                // keys; what the walk has seen already (everything up to last_idx's turn) gets the largest key and is skipped below
-                const unsigned long long seen = redo_visit_key(ph, last_idx, qx, qy, qz);
-                unsigned np2 = 64u; while (np2 < nc) np2 <<= 1;
-                for (unsigned t = lane; t < np2; t += 64u) {
-                    unsigned long long key = ~0ull;
-                    if (t < nc) { key = redo_visit_key(ph, c_slot[t], qx, qy, qz); if (key <= seen) key = ~0ull; }
-                    c_key[t] = key;
-                }
-                __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-                // bitonic sort of (key, slot), ascending
-                for (unsigned kk = 2u; kk <= np2; kk <<= 1) {
-                    for (unsigned jj = kk >> 1; jj > 0u; jj >>= 1) {
-                        for (unsigned t = lane; t < np2; t += 64u) {
-                            const unsigned u = t ^ jj;
-                            if (u > t) {
-                                const unsigned long long a = c_key[t], b = c_key[u];
-                                const bool up = (t & kk) == 0u;
-                                if ((a > b) == up) {
-                                    c_key[t] = b; c_key[u] = a;
-                                    const unsigned sa = c_slot[t]; c_slot[t] = c_slot[u]; c_slot[u] = sa;
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
-                    }
-                }
-                // the reference's `consider`, photon by photon in its order (dist2 from the reference's own record, photon.cpp:73-77)
-                for (unsigned t = 0; t < nc; ++t) {
-                    const unsigned long long key = c_key[t];
-                    if (key == ~0ull) break;
-                    const unsigned sl = (unsigned)__builtin_amdgcn_readfirstlane((int)c_slot[t]);
-                    const float4 rec = *reinterpret_cast<const float4*>(ph + sl);
-                    float d1 = rec.x - qx; float dist2 = d1 * d1;
-                    d1 = rec.y - qy; dist2 += d1 * d1;
-                    d1 = rec.z - qz; dist2 += d1 * d1;
-                    consider_uniform(hd, hi, lane, k, found, got_heap, r2, (int)sl, rl_f(dist2, 0));
-                }
-                ok = true;
-                }
-                    }
-                    if (ok) break;
-                }
+                if (WALK == 2 && got_heap && !tried && ++pops > redo_switch) { tried = true; want_keys = true; break; }
                 --sp;
                 const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)stk_i[sp]);
                 const float m0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(stk_m[sp])));
@@ -755,6 +667,107 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
                     __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
                 }
             }
+            if (WALK == 1 && gave_up) {
+                if (lane == 0) list2[atomicAdd(nlist2, 1u)] = (int32_t)i;
+                deferred = true;
+                break;
+            }
+            if (!want_keys) break;
+            // every photon that can still be accepted, in the reference's order; ok = false: too many, the walk goes on
+                    bool ok = false;
+                    {
+                const DevPhotonPos* __restrict__ pp2 = ph + 2 * (n + 1);
+                const DevPhotonPow* __restrict__ pq2 = reinterpret_cast<const DevPhotonPow*>(pp2 + (n + 2));
+                const float4* __restrict__ bx = reinterpret_cast<const float4*>(pq2 + (n + 1));
+                const unsigned un = (unsigned)n, nb = (unsigned)(n / 2);
+                const float R = r2;
+                if (lane == 0) { cnts[0] = 0u; cnts[1] = 0u; fq[0] = 1u; }
+                __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                unsigned ncur = 1u, cur = 0u;
+                bool over = false;
+                while (ncur > 0u && !over) {
+                    for (unsigned base = 0; base < ncur; base += 64u) {
+                        const unsigned node = base + lane < ncur ? fq[cur * REDO_FRONT + base + lane] : 0u;
+                        if (node != 0u) {
+                            const float4 rec = *reinterpret_cast<const float4*>(pp2 + node);
+                            float d1 = rec.x - qx; float dist2 = d1 * d1;
+                            d1 = rec.y - qy; dist2 += d1 * d1;
+                            d1 = rec.z - qz; dist2 += d1 * d1;
+                            if (dist2 < R && !((unsigned)__float_as_int(rec.w) & RT_PH_UNREACHABLE)) {
+                                const unsigned at = atomicAdd(&cnts[0], 1u);
+                                if (at < REDO_CAND) c_slot[at] = pq2[node].pad;
+                            }
+                            const unsigned c0 = 2u * node;
+                            for (unsigned c = c0; c <= c0 + 1u && c <= un; ++c) {
+                                bool want = true;
+                                if (c <= nb) {
+                                    const float4 lo = bx[2 * c], hi4 = bx[2 * c + 1];
+                                    const float dx = __builtin_fmaxf(__builtin_fmaxf(lo.x - qx, qx - hi4.x), 0.0f);
+                                    const float dy = __builtin_fmaxf(__builtin_fmaxf(lo.y - qy, qy - hi4.y), 0.0f);
+                                    const float dz = __builtin_fmaxf(__builtin_fmaxf(lo.z - qz, qz - hi4.z), 0.0f);
+                                    float bd = dx * dx; bd += dy * dy; bd += dz * dz;    // <= the dist2 of every photon inside (w_boxdist)
+                                    want = bd < R;
+                                }
+                                if (want) {
+                                    const unsigned at = atomicAdd(&cnts[1], 1u);
+                                    if (at < REDO_FRONT) fq[(cur ^ 1u) * REDO_FRONT + at] = c;
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                    const unsigned nnext = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[1]);
+                    const unsigned ncand_now = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[0]);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) cnts[1] = 0u;
+                    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                    over = nnext > REDO_FRONT || ncand_now > REDO_CAND;
+                    ncur = nnext; cur ^= 1u;
+                }
+                if (!over) {
+                const unsigned nc = (unsigned)__builtin_amdgcn_readfirstlane((int)cnts[0]);
+                // keys; what the walk has seen already (everything up to last_idx's turn) gets the largest key and is skipped below
+                const unsigned long long seen = redo_visit_key(ph, last_idx, qx, qy, qz);
+                unsigned np2 = 64u; while (np2 < nc) np2 <<= 1;
+                for (unsigned t = lane; t < np2; t += 64u) {
+                    unsigned long long key = ~0ull;
+                    if (t < nc) { key = redo_visit_key(ph, c_slot[t], qx, qy, qz); if (key <= seen) key = ~0ull; }
+                    c_key[t] = key;
+                }
+                __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                // bitonic sort of (key, slot), ascending
+                for (unsigned kk = 2u; kk <= np2; kk <<= 1) {
+                    for (unsigned jj = kk >> 1; jj > 0u; jj >>= 1) {
+                        for (unsigned t = lane; t < np2; t += 64u) {
+                            const unsigned u = t ^ jj;
+                            if (u > t) {
+                                const unsigned long long a = c_key[t], b = c_key[u];
+                                const bool up = (t & kk) == 0u;
+                                if ((a > b) == up) {
+                                    c_key[t] = b; c_key[u] = a;
+                                    const unsigned sa = c_slot[t]; c_slot[t] = c_slot[u]; c_slot[u] = sa;
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                // the reference's `consider`, photon by photon in its order (dist2 from the reference's own record, photon.cpp:73-77)
+                for (unsigned t = 0; t < nc; ++t) {
+                    const unsigned long long key = c_key[t];
+                    if (key == ~0ull) break;
+                    const unsigned sl = (unsigned)__builtin_amdgcn_readfirstlane((int)c_slot[t]);
+                    const float4 rec = *reinterpret_cast<const float4*>(ph + sl);
+                    float d1 = rec.x - qx; float dist2 = d1 * d1;
+                    d1 = rec.y - qy; dist2 += d1 * d1;
+                    d1 = rec.z - qz; dist2 += d1 * d1;
+                    consider_uniform(hd, hi, lane, k, found, got_heap, r2, (int)sl, rl_f(dist2, 0));
+                }
+                ok = true;
+                }
+                    }
+            if (ok) break;
+            }
         } else {
         float st1 = 0.f, st2 = 0.f;                                 // LocatePhoton's dist1 / this node's dist2 per level, level l in lane l
         bool done = n < 1;
@@ -805,6 +818,7 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
             }
         }
         }
+        if (deferred) continue;                                     // (the next launch does this query)
         // CalcIrradiance, photon.cpp:405-441: the sum over np.index[1 .. found] in that order
         float r = 0.f, g = 0.f, b = 0.f;
         if (found >= 8) {                                           // literal 8, photon.cpp:411
@@ -839,7 +853,7 @@ k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, con
 }
 
 size_t rtk_knn_fast_scratch_bytes(int64_t q) {
-    return (((size_t)q + 255) & ~(size_t)255) + 256 + 4 * (((size_t)q + 63) & ~(size_t)63) + rtk_photon_irr_wave_workspace(q);
+    return (((size_t)q + 255) & ~(size_t)255) + 256 + 2 * 4 * (((size_t)q + 63) & ~(size_t)63) + rtk_photon_irr_wave_workspace(q);      // flags, two counters, two lists, the sort
 }
 
 // Fast path: wave-shared kernel (mode 1) or cooperative kernel (mode 2), then the strict kernel redoes the flagged
@@ -856,8 +870,9 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
         // the wave-shared kernel lists the queries it leaves to the strict one: [count][indices] at the head of the workspace
         unsigned* nlist = (unsigned*)(d_flagged + (((size_t)q + 255) & ~(size_t)255));
         int32_t* list = (int32_t*)(nlist + 64);
-        void* work = (void*)(list + (((size_t)q + 63) & ~(size_t)63));
-        hipError_t e = hipMemsetAsync(nlist, 0, 4, st);
+        int32_t* list2 = list + (((size_t)q + 63) & ~(size_t)63);      // the flagged queries whose walk the first strict launch gives up (nlist[1] of them)
+        void* work = (void*)(list2 + (((size_t)q + 63) & ~(size_t)63));
+        hipError_t e = hipMemsetAsync(nlist, 0, 8, st);
         if (e != hipSuccess) return e;
         static const bool trace = getenv("RT_KNN_TRACE") != nullptr;      // per call: queries, flagged queries, ms of the main kernel and of the redo (synchronises)
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -879,18 +894,27 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
                 if (e != hipSuccess) return e;
                 rs = redo_st;
             }
+            // RT_KNN_REDO_WALK: 2 (default) = the stack walk (k_photon_knn_redo<1>), which gives up a walk that is still going
+            // RT_KNN_REDO_GIVEUP (25 000: an ordinary query needs ~6 000 in a 10 M-photon map, ~8 000 in 200 M) stack items after the reference's heap was built, then k_photon_knn_redo<2> over the
+            // queries given up: the walk again, finished by keys after RT_KNN_REDO_SWITCH (3 000) items.  Two launches because
+            // the kernel that holds the finish is a fifth slower per step of the walk (106 scalar registers), and ordinary
+            // queries -- all of the kNN line's -- never need it.  1 = the stack walk alone, 0 = the stackless walk.
             const int walk_env = [] { const char* v = getenv("RT_KNN_REDO_WALK"); return v ? atoi(v) : 2; }();
             const unsigned redo_switch = [] { const char* v = getenv("RT_KNN_REDO_SWITCH"); return v ? (unsigned)atoi(v) : (unsigned)REDO_SWITCH; }();
-            const bool old_walk = walk_env == 0;
-            if (!old_walk && walk_env != 1 && n < ((int64_t)1 << 30))
-                hipLaunchKernelGGL(k_photon_knn_redo<2>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
-                                   (const int32_t*)list, (const unsigned*)nlist, redo_switch);
-            else if (old_walk || n >= ((int64_t)1 << 30))
+            const int give_up = [] { const char* v = getenv("RT_KNN_REDO_GIVEUP"); return v ? atoi(v) : REDO_GIVEUP; }();
+            const bool old_walk = walk_env == 0 || n >= ((int64_t)1 << 30);
+            if (old_walk)
                 hipLaunchKernelGGL(k_photon_knn_redo<0>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
-                                   (const int32_t*)list, (const unsigned*)nlist, redo_switch);
-            else
+                                   (const int32_t*)list, (const unsigned*)nlist, 0u, -1, list2, nlist + 1);
+            else if (walk_env == 1)
                 hipLaunchKernelGGL(k_photon_knn_redo<1>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
-                                   (const int32_t*)list, (const unsigned*)nlist, redo_switch);
+                                   (const int32_t*)list, (const unsigned*)nlist, 0u, -1, list2, nlist + 1);
+            else {
+                hipLaunchKernelGGL(k_photon_knn_redo<1>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
+                                   (const int32_t*)list, (const unsigned*)nlist, 0u, give_up, list2, nlist + 1);
+                hipLaunchKernelGGL(k_photon_knn_redo<2>, dim3(512), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
+                                   (const int32_t*)list2, (const unsigned*)(nlist + 1), redo_switch, -1, nullptr, nullptr);
+            }
             if (trace) {
                 (void)hipEventRecord(ev[2], st); (void)hipEventSynchronize(ev[2]);
                 unsigned nl = 0; (void)hipMemcpy(&nl, nlist, 4, hipMemcpyDeviceToHost);

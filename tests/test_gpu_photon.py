@@ -207,7 +207,8 @@ def test_strict_redo_by_keys_is_the_references_list(monkeypatch):
     """The strict redo finishes a long walk by KEYS (kernels_photon.hip, WALK 2): the photons that can still be accepted come
     from the second heap, are sorted by the key of their turn in the reference's visiting order and go through the
     reference's `consider` in that order.  Here EVERY query is sent to the strict kernel (the wave-shared walk with a budget
-    of one node gives all of them up) and the switch to keys is forced at once, after 37 and after 400 stack items
+    of one node gives all of them up), the first strict launch hands every walk on as soon as the reference's heap exists
+    (RT_KNN_REDO_GIVEUP=0) and the second switches to keys at once, after 37 and after 400 stack items
     (RT_KNN_REDO_SWITCH): the irradiance must be the stack walk's bits (RT_KNN_REDO_WALK=1) and the oracle's CalcIrradiance
     bit for bit -- on a map with a coplanar third (the caustic map's shape, where the walk is long), a lattice with
     duplicates (ties) and queries ON photons."""
@@ -236,8 +237,10 @@ def test_strict_redo_by_keys_is_the_references_list(monkeypatch):
             got = {}
             for walk, switch in (("1", None), ("2", "0"), ("2", "37"), ("2", "400"), ("2", None)):
                 monkeypatch.setenv("RT_KNN_REDO_WALK", walk)
-                if switch is None: monkeypatch.delenv("RT_KNN_REDO_SWITCH", raising=False)
-                else: monkeypatch.setenv("RT_KNN_REDO_SWITCH", switch)
+                if switch is None:
+                    monkeypatch.delenv("RT_KNN_REDO_SWITCH", raising=False); monkeypatch.delenv("RT_KNN_REDO_GIVEUP", raising=False)
+                else:        # the first launch gives every walk up as soon as the heap exists, the second switches to keys after `switch` items
+                    monkeypatch.setenv("RT_KNN_REDO_SWITCH", switch); monkeypatch.setenv("RT_KNN_REDO_GIVEUP", "0")
                 got[(walk, switch)] = s.photon_irradiance(abi.RT_PMAP_GLOBAL, qp, qn, k, maxd)
             for key, rgb in got.items():
                 assert rgb.tobytes() == want.tobytes(), (k, maxd, key, int((rgb.view(np.uint32) != want.view(np.uint32)).any(-1).sum()))

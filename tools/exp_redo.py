@@ -36,8 +36,9 @@ for shape in ("walls", "coplanar"):
             if walk == "0" and (shape == "coplanar" and radius >= 0.1):
                 continue                                                   # (the stackless walk of a coplanar map: minutes)
             os.environ["RT_KNN_REDO_WALK"] = walk[0]
-            os.environ.pop("RT_KNN_REDO_SWITCH", None)
-            if "/" in walk: os.environ["RT_KNN_REDO_SWITCH"] = walk.split("/")[1]     # the switch to keys after that many stack items
+            os.environ.pop("RT_KNN_REDO_SWITCH", None); os.environ.pop("RT_KNN_REDO_GIVEUP", None)
+            if "/" in walk:      # every walk is given up as soon as the heap exists; the second launch switches to keys after that many stack items
+                os.environ["RT_KNN_REDO_GIVEUP"] = "0"; os.environ["RT_KNN_REDO_SWITCH"] = walk.split("/")[1]
             out = torch.zeros((nq, 3), dtype=torch.float32, device="cuda")
             torch.cuda.synchronize(); t0 = time.perf_counter()
             abi.check(g.L.rt_photon_irradiance_dev(g.h, 0, dq.data_ptr(), dn.data_ptr(), nq, k, radius, out.data_ptr(), None))
