@@ -1,8 +1,5 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-for v in "RT_KNN_REDO_WALK=1" "RT_KNN_REDO_WALK=2" "RT_KNN_REDO_WALK=1" "RT_KNN_REDO_WALK=2"; do
-  echo "== $v 10M / 200M / frame"
-  env $v timeout -k 10 200 python -u tools/exp_knn.py 2>/dev/null | tail -1 | cut -c1-100 || exit $?
-  env $v timeout -k 10 300 python -u tools/exp_knn.py 2e8 2>/dev/null | tail -1 | cut -c1-100 || exit $?
-  env $v timeout -k 10 300 python -u tools/exp_pframe.py full 2>/dev/null | tail -1 | cut -c1-130 || exit $?
+for v in "RT_PRIMARY_XCD_BANDS=0" "RT_PRIMARY_XCD_BANDS=4" "RT_PRIMARY_XCD_BANDS=15" "RT_PRIMARY_XCD_BANDS=60" "RT_PRIMARY_XCD_BANDS=240"; do
+  echo "== $v"; env $v timeout -k 10 200 python -u tools/exp_primary.py 10 2>/dev/null | cut -c1-90 || exit $?
 done
