@@ -186,6 +186,11 @@ def make_roofline(workload, kernel, avg_ms, units_per_launch, alg_bytes, wave_by
             fr["scalar_issue"] = (sc / t / 1e9, SCALAR_PEAK_GINST, "G instructions/s")
     if fr:
         bound = max(fr, key=lambda k: fr[k][0] / fr[k][1])
+        # a kernel whose HBM TRAFFIC (lines moved, useful or not) is a larger share of its peak than either issue rate is of
+        # theirs is bound by memory, whatever share of those lines the algorithm asked for: `bound` says so, `achieved` stays
+        # the useful bytes per second, and `hbm_traffic_frac` below is the traffic's own share
+        if traffic and "hbm" in fr and traffic / t / 1e9 / HBM_PEAK_GBS > fr[bound][0] / fr[bound][1]:
+            bound = "hbm"
         ach, peak, unit = fr[bound]
         note = None
     else:      # no counters committed for this kernel: the SURVEY 8d figure alone, capped so that it stays a fraction
