@@ -517,7 +517,7 @@ __device__ __forceinline__ unsigned long long redo_visit_key(const DevPhoton* __
 #define REDO_CAND 1024
 #define REDO_FRONT 1024
 #define REDO_SWITCH 3000
-#define REDO_GIVEUP 25000
+#define REDO_GIVEUP 16000
 template <int WALK>
 __global__ void __launch_bounds__(64)
 k_photon_knn_redo(const DevPhoton* __restrict__ ph, int64_t n, int64_t half, const float* __restrict__ pos3,
@@ -895,13 +895,16 @@ hipError_t rtk_photon_knn_fast(const DevPhoton* ph, int64_t n, int64_t half, con
                 rs = redo_st;
             }
             // RT_KNN_REDO_WALK: 2 (default) = the stack walk (k_photon_knn_redo<1>), which gives up a walk that is still going
-            // RT_KNN_REDO_GIVEUP (25 000: an ordinary query needs ~6 000 in a 10 M-photon map, ~8 000 in 200 M) stack items after the reference's heap was built, then k_photon_knn_redo<2> over the
+            // RT_KNN_REDO_GIVEUP (16 000, + 2 000 per doubling of the map beyond 2^28 photons: an ordinary query's walk has ~6 000 in a
+            // 10 M-photon map and between 9 000 and 12 000 in 200 M -- at 9 000 that map's line loses 30 % to walks handed on for
+            // nothing, at 12 000 / 16 000 / 25 000 it is unchanged and config 4's frame takes 2 272 / 2 279 / 2 305 ms) stack items after the reference's heap was built, then k_photon_knn_redo<2> over the
             // queries given up: the walk again, finished by keys after RT_KNN_REDO_SWITCH (3 000) items.  Two launches because
             // the kernel that holds the finish is a fifth slower per step of the walk (106 scalar registers), and ordinary
             // queries -- all of the kNN line's -- never need it.  1 = the stack walk alone, 0 = the stackless walk.
             const int walk_env = [] { const char* v = getenv("RT_KNN_REDO_WALK"); return v ? atoi(v) : 2; }();
             const unsigned redo_switch = [] { const char* v = getenv("RT_KNN_REDO_SWITCH"); return v ? (unsigned)atoi(v) : (unsigned)REDO_SWITCH; }();
-            const int give_up = [] { const char* v = getenv("RT_KNN_REDO_GIVEUP"); return v ? atoi(v) : REDO_GIVEUP; }();
+            int give_up = [] { const char* v = getenv("RT_KNN_REDO_GIVEUP"); return v ? atoi(v) : -2; }();
+            if (give_up == -2) { give_up = REDO_GIVEUP; for (int64_t m = (int64_t)1 << 28; m < n; m <<= 1) give_up += 2000; }
             const bool old_walk = walk_env == 0 || n >= ((int64_t)1 << 30);
             if (old_walk)
                 hipLaunchKernelGGL(k_photon_knn_redo<0>, dim3(2048), dim3(64), 0, rs, ph, n, half, d_pos3, d_nrm3, k, maxDist, d_rgb, d_tables,
