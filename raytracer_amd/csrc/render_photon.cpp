@@ -79,13 +79,27 @@ int render_photon_impl(rt_scene* s, const rt_camera* cam, const rt_params* p, ui
     std::vector<int32_t> tiles;
     rank_microtiles(*cam, *p, tiles);
     const int64_t ntiles = (int64_t)tiles.size();
-    // chunk: about 2^21 samples -- a 1080p frame whole (105 M gather rays, 22 GB of queues and 0.8 GB of occlusion bytes at the
-    // reference's settings; the memory is taken for the frames that need it, a small frame is one small chunk).  The radiance
-    // estimate is why: a call sorts ITS queries along the Morton curve, so the more queries a call holds the closer the 64 of
-    // a wave lie and the more of their walks the caches share -- BASELINE configuration 4 at full size, per frame:
-    // 2^17 3 561 ms, 2^18 3 187 (the default until round 3), 2^19 2 883, 2^20 2 630, 2^21 2 533, 2^22 the same (one chunk).
-    // RT_PM_CHUNK_LOG2 = 12 .. 22 overrides (2^18: 2.7 GB of queues).
-    static const int chunk_log2 = [] { const char* e = getenv("RT_PM_CHUNK_LOG2"); const int v = e ? atoi(e) : 21; return v < 12 ? 12 : (v > 22 ? 22 : v); }();
+    // chunk: about 2^21 samples -- a 1080p frame whole: 105 M gather rays, and a gather arena of 84 GB at the reference's settings
+    // (50 gather rays per sample, room for two refractive doublings, 202 B per entry) beside 0.8 GB of occlusion bytes and ~6 GB
+    // of radiance-estimate workspace; the memory is taken for the frames that need it, a small frame is one small chunk.  The
+    // radiance estimate is why: a call sorts ITS queries along the Morton curve, so the more queries a call holds the closer the
+    // 64 of a wave lie and the more of their walks the caches share -- BASELINE configuration 4 at full size, per frame:
+    // 2^17 3 561 ms, 2^18 3 187 (the default until round 3; 10.6 GB), 2^19 2 883, 2^20 2 630, 2^21 2 533, 2^22 the same (one chunk).
+    // RT_PM_CHUNK_LOG2 = 12 .. 22 overrides; without it the chunk is halved until its arena fits into half of the device memory
+    // that is free now (counting what this scene's arena already holds), so a crowded GPU gets smaller chunks, not RT_E_NOMEM.
+    static const int chunk_env = [] { const char* e = getenv("RT_PM_CHUNK_LOG2"); const int v = e ? atoi(e) : 0; return v == 0 ? 0 : (v < 12 ? 12 : (v > 22 ? 22 : v)); }();
+    int chunk_log2 = chunk_env ? chunk_env : 21;
+    if (!chunk_env) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double room = 0.5 * ((double)free_b + (double)s->scratch_cap[P_G_SLOTS]);
+            auto arena = [&](int lg) {
+                const int64_t tl = std::min<int64_t>(ntiles, std::max<int64_t>(1, ((int64_t)1 << lg) / (64 * ntap)));
+                return (double)(tl * ntap * 64) * (double)std::max(G, 1) * 4.0 * 202.0;      // two doublings: the worst case of depth 0
+            };
+            while (chunk_log2 > 14 && arena(chunk_log2) > room) --chunk_log2;
+        }
+    }
     const int64_t chunk_tiles = std::max<int64_t>(1, ((int64_t)1 << chunk_log2) / (64 * ntap));
     const int64_t T = std::min(ntiles, chunk_tiles);
     const int64_t nps = T * 64, nsmp = nps * ntap;
